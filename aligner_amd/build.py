@@ -1,0 +1,41 @@
+"""Builds aligner_amd/lib/libaligner_hip.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the dev container; the built .so travels to the GPU box
+with the repo snapshot.  `python -m aligner_amd.build [--force] [--remarks]`.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libaligner_hip.so")
+SOURCES = ["aln_kernels.hip", "aln_host.hip"]
+HEADERS = ["aln_device.h", os.path.join("..", "..", "include", "aligner_hip.h")]
+# -ffp-contract=off: the f64 kernels must be the reference's add/sub/max/compare, never an fma
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, remarks=False):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if remarks else []) + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, remarks="--remarks" in sys.argv))

@@ -1,0 +1,87 @@
+// aln_device.h -- structures shared by the host driver and the gfx950 kernels.
+//
+// HBM data layout of a staged batch (all offsets in bytes unless noted):
+//   seqs    : u8 residue codes of every query / target, packed back to back
+//   descs   : PairDesc[n]           one record per pair
+//   order   : u32[n]                pair indices sorted by M*N descending (LPT order for the work queue)
+//   dirs    : packed 2-bit directions, one region per pair (PairDesc.dir_off), "skewed strip" layout:
+//               strip s = rows s*512+1 .. (s+1)*512 of H, handled by one wave; lane l owns R consecutive rows
+//               (R = 8 for every full strip; the last strip picks the smallest R in {1,2,4,8} covering its rows);
+//               lane l computes column x at wave step k = (x-1) + l (anti-diagonal skew);
+//               one u32 per lane holds R rows x (16/R) consecutive steps: word index = (k / SPB) * 64 + lane,
+//               SPB = 16/R, cell (row r, step k) at bits 2*((k % SPB)*R + r).  A wave therefore stores 256
+//               contiguous bytes per SPB steps -- fully coalesced, 0.25 B per cell.
+//             serial-order fallback (layout 1): plain row-major, row stride (N+4)/4 bytes, 4 cells per byte.
+//   results : aln_pair_result[n]
+//   tb      : aligned code strings, pair i at tb_off: query string then (M+N+2 bytes later) target string
+//   scratch : per wave: strip boundary row (score type, N+66 entries), advice bytes, bottom-row zero bytes
+#pragma once
+#include <stdint.h>
+
+#include "../../include/aligner_hip.h"
+
+#define ALN_STRIP_ROWS 512      // rows per full strip (64 lanes x R=8)
+#define ALN_LAYOUT_SKEW 0u
+#define ALN_LAYOUT_ROWMAJOR 1u
+
+struct PairDesc {
+    uint64_t q_off, t_off;   // into seqs
+    uint32_t N, M;           // query / target length
+    uint64_t dir_off;        // into dirs, multiple of 256
+    uint64_t tb_off;         // into tb
+    uint64_t h_off;          // element offset into the optional H matrix buffer
+    int32_t status;          // pre-validation status; != 0 -> kernels skip the pair
+    uint32_t layout;         // written by the fill kernel
+};
+
+struct FillArgs {
+    const uint8_t *seqs;
+    PairDesc *descs;
+    const uint32_t *order;
+    uint32_t n_pairs;
+    uint32_t *counter;        // work-queue head, zeroed before every launch
+    uint8_t *dirs;
+    aln_pair_result *results;
+    uint8_t *scratch;         // per-wave scratch base
+    uint64_t scratch_stride;  // bytes per wave
+    uint32_t max_len;         // max over pairs of max(N, M): sizes the scratch arrays
+    const void *matrix;       // device copy, contiguous rows x cols, int32 or double
+    uint32_t rows, cols;
+    double del, ext;
+    int32_t semantics;
+    uint32_t max_passes;
+    uint32_t force_serial;
+    void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
+    uint8_t blank;
+};
+
+struct TraceArgs {
+    const uint8_t *seqs;
+    const PairDesc *descs;
+    uint32_t n_pairs;
+    const uint8_t *dirs;
+    aln_pair_result *results;
+    uint8_t *tb;
+    int32_t semantics;
+    uint8_t blank;
+};
+
+// rows handled per lane in the strip that starts `rem` rows before the end of the target
+__host__ __device__ inline int aln_pick_r(uint32_t rem)
+{
+    return rem > 256 ? 8 : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+}
+__host__ __device__ inline uint32_t aln_num_strips(uint32_t M) { return (M + ALN_STRIP_ROWS - 1) / ALN_STRIP_ROWS; }
+// bytes of one full (R = 8) strip region: steps N+63, 2 steps per word, 64 words (256 B) per block
+__host__ __device__ inline uint64_t aln_strip_bytes(uint32_t N) { return (uint64_t)((N + 63 + 1) / 2) * 256u; }
+__host__ __device__ inline uint64_t aln_rowmajor_bytes(uint32_t N, uint32_t M)
+{
+    return (uint64_t)(M + 1) * ((N + 4) / 4);
+}
+__host__ __device__ inline uint64_t aln_dir_bytes(uint32_t N, uint32_t M)
+{
+    uint64_t a = (uint64_t)aln_num_strips(M) * aln_strip_bytes(N);
+    uint64_t b = aln_rowmajor_bytes(N, M);
+    uint64_t m = a > b ? a : b;
+    return (m + 255) & ~(uint64_t)255;
+}

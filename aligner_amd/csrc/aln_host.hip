@@ -1,0 +1,463 @@
+// aln_host.hip -- host side of the C ABI declared in include/aligner_hip.h.
+//
+// Batch packing (validation, LPT ordering, direction-region layout), HBM staging, kernel launches on a HIP
+// stream, result fetch.  One context per process per GPU; multi-GPU runs are one process per GPU (the Python
+// driver shards pairs across ranks and gathers the 48-byte summaries with RCCL through torch.distributed).
+// There is NO CPU implementation of the DP here: if the device or the kernels are unavailable every entry point
+// fails with ALN_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "aln_device.h"
+
+extern "C" void aln_launch_fill(const FillArgs *a, int is_int, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
+extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
+extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
+                                  uint64_t cells, hipStream_t s);
+
+static thread_local std::string g_err;
+
+struct aln_ctx {
+    int device = 0;
+    int cus = 0;
+    size_t hbm = 0;
+    char name[128] = {0};
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+};
+
+struct aln_batch {
+    aln_ctx *ctx = nullptr;
+    aln_params params{};
+    size_t n = 0;
+    bool is_int = true;
+    uint64_t cells = 0;
+    uint64_t dir_bytes = 0;
+    uint64_t tb_bytes = 0;
+    uint32_t max_len = 0;
+    uint32_t grid = 0;
+    uint64_t scratch_stride = 0;
+    uint32_t lds_bytes = 0;
+    std::vector<PairDesc> descs;
+    // device
+    uint8_t *d_seqs = nullptr;
+    PairDesc *d_descs = nullptr;
+    uint32_t *d_order = nullptr;
+    uint32_t *d_counter = nullptr;
+    uint8_t *d_dirs = nullptr;
+    aln_pair_result *d_results = nullptr;
+    uint8_t *d_tb = nullptr;
+    uint8_t *d_scratch = nullptr;
+    void *d_matrix = nullptr;
+    void *d_hmat = nullptr;
+    uint64_t hmat_elems = 0;
+    hipStream_t last_stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    uint32_t fill_launches = 0;
+};
+
+static int fail(hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    g_err = buf;
+    return e == hipErrorOutOfMemory ? ALN_ERR_OOM : ALN_ERR_DEVICE;
+}
+#define HIPCHK(call)                                         \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return fail(e_, #call);        \
+    } while (0)
+
+extern "C" const char *aln_last_error(void) { return g_err.c_str(); }
+extern "C" int aln_abi_version(void) { return ALN_ABI_VERSION; }
+
+extern "C" aln_ctx *aln_create(int device_id, int *status)
+{
+    int st = ALN_OK;
+    aln_ctx *c = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no HIP device visible";
+        st = ALN_ERR_DEVICE;
+    } else if (device_id < 0 || device_id >= ndev) {
+        g_err = "device id out of range";
+        st = ALN_ERR_INVALID_ARGUMENT;
+    } else {
+        hipDeviceProp_t prop;
+        if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+            st = fail(e, "hipSetDevice/hipGetDeviceProperties");
+        } else {
+            c = new aln_ctx();
+            c->device = device_id;
+            c->cus = prop.multiProcessorCount;
+            c->hbm = prop.totalGlobalMem;
+            snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+            if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+                st = fail(e, "hipStreamCreate");
+                delete c;
+                c = nullptr;
+            }
+        }
+    }
+    if (status) *status = st;
+    return c;
+}
+
+extern "C" void aln_destroy(aln_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int aln_device_info(aln_ctx *ctx, int *cus, size_t *hbm, char *name, size_t cap)
+{
+    if (!ctx) return ALN_ERR_INVALID_ARGUMENT;
+    if (cus) *cus = ctx->cus;
+    if (hbm) *hbm = ctx->hbm;
+    if (name && cap) { strncpy(name, ctx->name, cap - 1); name[cap - 1] = 0; }
+    return ALN_OK;
+}
+
+static bool integral(double v) { return std::isfinite(v) && v == std::floor(v) && std::fabs(v) < 1e9; }
+
+static void batch_free(aln_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    void *ptrs[] = {b->d_seqs, b->d_descs, b->d_order, b->d_counter, b->d_dirs, b->d_results, b->d_tb, b->d_scratch,
+                    b->d_matrix, b->d_hmat};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+extern "C" void aln_batch_destroy(aln_batch *b) { batch_free(b); }
+
+static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, const uint64_t *q_off,
+                       const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n, bool want_h,
+                       aln_batch **out)
+{
+    *out = nullptr;
+    if (!ctx || !p || (n && (!seqs || !q_off || !q_len || !t_off || !t_len))) { g_err = "null argument"; return ALN_ERR_INVALID_ARGUMENT; }
+    if (p->semantics < ALN_CORE_GLOBAL || p->semantics > ALN_LEGACY_LOCAL) { g_err = "bad semantics"; return ALN_ERR_INVALID_ARGUMENT; }
+    const bool core = p->semantics == ALN_CORE_GLOBAL || p->semantics == ALN_CORE_LOCAL;
+    // simple/mod.rs:49-51 / :175-177
+    if (core && p->heuristics_present) return ALN_ERR_UNNECESSARY_ARGUMENT;
+    if (!p->matrix || p->rows == 0 || p->cols == 0) { g_err = "matrix missing"; return ALN_ERR_INVALID_ARGUMENT; }
+    if ((uint64_t)p->rows * p->cols > 4096) { g_err = "substitution matrix larger than 4096 entries"; return ALN_ERR_UNSUPPORTED; }
+    if (n > 0xFFFFFFF0ull) { g_err = "too many pairs"; return ALN_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(ctx->device));
+
+    aln_batch *b = new aln_batch();
+    b->ctx = ctx;
+    b->params = *p;
+    b->params.matrix = nullptr;
+    b->n = n;
+
+    // ---- compact the matrix, pick the arithmetic
+    const uint32_t rows = p->rows, cols = p->cols;
+    const int64_t rs = p->row_stride ? p->row_stride : (int64_t)cols;
+    std::vector<double> md((size_t)rows * cols);
+    double maxabs = std::max(std::fabs(p->del), std::fabs(p->ext));
+    bool all_int = integral(p->del) && (core ? integral(p->ext) : true);
+    for (uint32_t r = 0; r < rows; ++r)
+        for (uint32_t c = 0; c < cols; ++c) {
+            double v = p->matrix[(int64_t)r * rs + c];
+            md[(size_t)r * cols + c] = v;
+            all_int = all_int && integral(v);
+            maxabs = std::max(maxabs, std::fabs(v));
+        }
+    if (!core && !all_int) { g_err = "legacy semantics are i32: del and matrix must be integral"; batch_free(b); return ALN_ERR_INVALID_ARGUMENT; }
+    if (!core && p->force_f64) { g_err = "legacy semantics have no f64 form"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
+
+    // ---- per-pair validation + layout
+    b->descs.resize(n);
+    uint64_t dir_total = 0, tb_total = 0, hm_total = 0, cells = 0;
+    uint32_t max_len = 1;
+    uint64_t max_span = 0;
+    for (size_t i = 0; i < n; ++i) {
+        PairDesc &d = b->descs[i];
+        memset(&d, 0, sizeof d);
+        d.q_off = q_off[i];
+        d.t_off = t_off[i];
+        if (q_len[i] > 0x7FFFFFF0ull || t_len[i] > 0x7FFFFFF0ull) { g_err = "sequence too long"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
+        d.N = (uint32_t)q_len[i];
+        d.M = (uint32_t)t_len[i];
+        d.status = ALN_OK;
+        if (d.N == 0 || d.M == 0) d.status = ALN_ERR_EMPTY_SEQUENCE;          // reference panics
+        else {
+            const uint8_t *q = seqs + d.q_off, *t = seqs + d.t_off;
+            for (uint32_t k = 0; k < d.N && d.status == ALN_OK; ++k) if (q[k] >= cols) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
+            for (uint32_t k = 0; k < d.M && d.status == ALN_OK; ++k) if (t[k] >= rows) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
+        }
+        if (d.status != ALN_OK) continue;
+        d.dir_off = dir_total;
+        dir_total += aln_dir_bytes(d.N, d.M);
+        d.tb_off = tb_total;
+        tb_total += 2ull * ((uint64_t)d.N + d.M + 2);
+        if (want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
+        cells += (uint64_t)d.N * d.M;
+        max_len = std::max(max_len, std::max(d.N, d.M));
+        max_span = std::max(max_span, (uint64_t)d.N + d.M + 2);
+    }
+    b->cells = cells;
+    b->dir_bytes = dir_total;
+    b->tb_bytes = tb_total;
+    b->max_len = max_len;
+    b->hmat_elems = hm_total;
+    // integer kernels are exact iff every value is integral and |H| cannot leave i32
+    b->is_int = all_int && !p->force_f64 && maxabs * (double)max_span < 1073741824.0;
+    if (!core && !b->is_int) { g_err = "legacy scores overflow i32 for these lengths"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
+
+    // ---- LPT order: largest pairs first into the device work queue
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
+        return (uint64_t)b->descs[a].N * b->descs[a].M > (uint64_t)b->descs[c].N * b->descs[c].M;
+    });
+
+    // ---- grid: persistent waves, 4 per workgroup
+    const uint32_t wg_needed = (uint32_t)((n + 3) / 4);
+    b->grid = std::max(1u, std::min(wg_needed, (uint32_t)ctx->cus * 4u));
+    const uint64_t sc_size = b->is_int ? 4 : 8;
+    const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
+    const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
+    b->scratch_stride = brow_bytes + 2 * adv_bytes;
+    b->lds_bytes = (uint32_t)((uint64_t)rows * cols * sc_size);
+
+    // ---- device allocations + H2D
+    uint64_t seq_bytes = 0;
+    for (size_t i = 0; i < n; ++i) {
+        seq_bytes = std::max(seq_bytes, q_off[i] + q_len[i]);
+        seq_bytes = std::max(seq_bytes, t_off[i] + t_len[i]);
+    }
+    auto dmalloc = [&](void **ptr, uint64_t bytes) { return hipMalloc(ptr, std::max<uint64_t>(bytes, 256)); };
+    hipError_t e;
+#define BCHK(call) if ((e = (call)) != hipSuccess) { int st_ = fail(e, #call); batch_free(b); return st_; }
+    BCHK(dmalloc((void **)&b->d_seqs, seq_bytes + 64));
+    BCHK(dmalloc((void **)&b->d_descs, n * sizeof(PairDesc)));
+    BCHK(dmalloc((void **)&b->d_order, n * sizeof(uint32_t)));
+    BCHK(dmalloc((void **)&b->d_counter, 256));
+    BCHK(dmalloc((void **)&b->d_dirs, dir_total));
+    BCHK(dmalloc((void **)&b->d_results, n * sizeof(aln_pair_result)));
+    BCHK(dmalloc((void **)&b->d_tb, tb_total));
+    BCHK(dmalloc((void **)&b->d_scratch, (uint64_t)b->grid * 4 * b->scratch_stride));
+    BCHK(dmalloc((void **)&b->d_matrix, (uint64_t)rows * cols * sc_size));
+    if (want_h) BCHK(dmalloc((void **)&b->d_hmat, hm_total * sc_size));
+    if (n) {
+        BCHK(hipMemcpy(b->d_seqs, seqs, seq_bytes, hipMemcpyHostToDevice));
+        BCHK(hipMemcpy(b->d_descs, b->descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice));
+        BCHK(hipMemcpy(b->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (b->is_int) {
+        std::vector<int32_t> mi(md.size());
+        for (size_t i = 0; i < md.size(); ++i) mi[i] = (int32_t)md[i];
+        BCHK(hipMemcpy(b->d_matrix, mi.data(), mi.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        BCHK(hipMemcpy(b->d_matrix, md.data(), md.size() * 8, hipMemcpyHostToDevice));
+    }
+    BCHK(hipMemset(b->d_results, 0, std::max<uint64_t>(n * sizeof(aln_pair_result), 1)));
+#undef BCHK
+    *out = b;
+    return ALN_OK;
+}
+
+extern "C" aln_batch *aln_batch_create(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs,
+                                       const uint64_t *q_off, const uint64_t *q_len, const uint64_t *t_off,
+                                       const uint64_t *t_len, size_t n_pairs, int *status)
+{
+    aln_batch *b = nullptr;
+    int st = batch_build(ctx, params, seqs, q_off, q_len, t_off, t_len, n_pairs, false, &b);
+    if (status) *status = st;
+    return b;
+}
+
+extern "C" void aln_batch_enable_timing(aln_batch *b, int on)
+{
+    if (!b) return;
+    b->timing = on != 0;
+    if (b->timing && !b->ev[0]) {
+        (void)hipSetDevice(b->ctx->device);
+        for (auto &e : b->ev) (void)hipEventCreate(&e);
+    }
+}
+
+extern "C" int aln_batch_run(aln_batch *b, void *stream)
+{
+    if (!b) return ALN_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : b->ctx->stream;
+    b->last_stream = s;
+    if (b->n == 0) return ALN_OK;
+    HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, s));
+    FillArgs fa{};
+    fa.seqs = b->d_seqs; fa.descs = b->d_descs; fa.order = b->d_order; fa.n_pairs = (uint32_t)b->n;
+    fa.counter = b->d_counter; fa.dirs = b->d_dirs; fa.results = b->d_results;
+    fa.scratch = b->d_scratch; fa.scratch_stride = b->scratch_stride; fa.max_len = b->max_len;
+    fa.matrix = b->d_matrix; fa.rows = b->params.rows; fa.cols = b->params.cols;
+    fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
+    fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
+    fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[0], s));
+    aln_launch_fill(&fa, b->is_int ? 1 : 0, b->grid, b->lds_bytes, s);
+    HIPCHK(hipGetLastError());
+    b->fill_launches = 1;
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[1], s));
+    const uint32_t outs = b->params.outputs ? b->params.outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
+    if (outs & ALN_OUT_TRACEBACK) {
+        TraceArgs ta{};
+        ta.seqs = b->d_seqs; ta.descs = b->d_descs; ta.n_pairs = (uint32_t)b->n; ta.dirs = b->d_dirs;
+        ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code;
+        aln_launch_traceback(&ta, s);
+        HIPCHK(hipGetLastError());
+    }
+    if (b->timing) HIPCHK(hipEventRecord(b->ev[2], s));
+    return ALN_OK;
+}
+
+extern "C" int aln_batch_sync(aln_batch *b)
+{
+    if (!b) return ALN_ERR_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipStreamSynchronize(b->last_stream ? b->last_stream : b->ctx->stream));
+    return ALN_OK;
+}
+
+extern "C" int aln_batch_timing(aln_batch *b, double *fill_ms, double *tb_ms, uint32_t *fill_launches)
+{
+    if (!b || !b->timing || !b->ev[0]) return ALN_ERR_INVALID_ARGUMENT;
+    float f = 0, t = 0;
+    HIPCHK(hipEventSynchronize(b->ev[2]));
+    HIPCHK(hipEventElapsedTime(&f, b->ev[0], b->ev[1]));
+    HIPCHK(hipEventElapsedTime(&t, b->ev[1], b->ev[2]));
+    if (fill_ms) *fill_ms = f;
+    if (tb_ms) *tb_ms = t;
+    if (fill_launches) *fill_launches = b->fill_launches;
+    return ALN_OK;
+}
+
+extern "C" int aln_batch_fetch(aln_batch *b, aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off)
+{
+    if (!b || !results) return ALN_ERR_INVALID_ARGUMENT;
+    int st = aln_batch_sync(b);
+    if (st != ALN_OK) return st;
+    if (b->n == 0) return ALN_OK;
+    HIPCHK(hipMemcpy(results, b->d_results, b->n * sizeof(aln_pair_result), hipMemcpyDeviceToHost));
+    if (tb_buf && tb_off && b->tb_bytes) {
+        std::vector<uint8_t> h(b->tb_bytes);
+        HIPCHK(hipMemcpy(h.data(), b->d_tb, b->tb_bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < b->n; ++i) {
+            const PairDesc &d = b->descs[i];
+            if (results[i].status != ALN_OK) continue;
+            const uint64_t cap = (uint64_t)d.N + d.M + 2;
+            memcpy(tb_buf + tb_off[i], h.data() + d.tb_off, results[i].aln_len);
+            memcpy(tb_buf + tb_off[i] + cap, h.data() + d.tb_off + cap, results[i].aln_len);
+        }
+    }
+    return ALN_OK;
+}
+
+extern "C" uint64_t aln_batch_cells(const aln_batch *b) { return b ? b->cells : 0; }
+extern "C" size_t aln_batch_size(const aln_batch *b) { return b ? b->n : 0; }
+extern "C" void *aln_batch_results_device(aln_batch *b) { return b ? b->d_results : nullptr; }
+extern "C" uint64_t aln_batch_direction_bytes(const aln_batch *b)
+{
+    if (!b) return 0;
+    // bytes the fill kernel actually stores: per strip, ceil(steps / SPB) blocks of 256 B
+    uint64_t total = 0;
+    for (const PairDesc &d : b->descs) {
+        if (d.status != ALN_OK) continue;
+        const uint32_t ns = aln_num_strips(d.M);
+        for (uint32_t s = 0; s < ns; ++s) {
+            const bool last = s + 1 == ns;
+            const uint32_t rem = d.M - s * ALN_STRIP_ROWS;
+            const int R = last ? aln_pick_r(rem) : 8;
+            const uint32_t rows = std::min<uint32_t>(rem, 64u * R), L = (rows + R - 1) / R, spb = 16 / R;
+            total += (uint64_t)((d.N + L - 1 + spb - 1) / spb) * 256u;
+        }
+    }
+    return total;
+}
+
+extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
+                               const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
+                               aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off)
+{
+    aln_batch *b = nullptr;
+    int st = batch_build(ctx, params, seqs, q_off, q_len, t_off, t_len, n_pairs, false, &b);
+    if (st != ALN_OK) return st;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        st = aln_batch_run(b, nullptr);
+        if (st == ALN_OK) st = aln_batch_fetch(b, results, tb_buf, tb_off);
+    }
+    batch_free(b);
+    return st;
+}
+
+extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint8_t *query, size_t N,
+                              const uint8_t *target, size_t M, aln_pair_result *out, uint8_t *q_aln, uint8_t *t_aln,
+                              uint8_t *directions, double *h_matrix)
+{
+    if (!ctx || !params || !out) { g_err = "null argument"; return ALN_ERR_INVALID_ARGUMENT; }
+    std::vector<uint8_t> seqs(N + M + 1);
+    if (N) memcpy(seqs.data(), query, N);
+    if (M) memcpy(seqs.data() + N, target, M);
+    const uint64_t qo = 0, ql = N, to = N, tl = M;
+    aln_params p = *params;
+    p.outputs = (params->outputs ? params->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK));
+    if (q_aln && t_aln) p.outputs |= ALN_OUT_TRACEBACK;
+    aln_batch *b = nullptr;
+    int st = batch_build(ctx, &p, seqs.data(), &qo, &ql, &to, &tl, 1, h_matrix != nullptr, &b);
+    if (st != ALN_OK) { memset(out, 0, sizeof *out); out->status = st; return st; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    st = aln_batch_run(b, nullptr);
+    std::vector<uint8_t> tb(2 * (N + M + 2));
+    const uint64_t tbo = 0;
+    if (st == ALN_OK) st = aln_batch_fetch(b, out, tb.data(), &tbo);
+    if (st == ALN_OK && out->status == ALN_OK) {
+        if (q_aln && t_aln) {
+            memcpy(q_aln, tb.data(), out->aln_len);
+            memcpy(t_aln, tb.data() + (N + M + 2), out->aln_len);
+        }
+        const uint64_t cells = (uint64_t)(N + 1) * (M + 1);
+        if (directions) {
+            uint8_t *d_out = nullptr;
+            hipError_t e = hipMalloc((void **)&d_out, cells);
+            if (e != hipSuccess) { st = fail(e, "hipMalloc(directions)"); }
+            else {
+                aln_launch_unpack(b->d_dirs, b->d_descs, 0, p.semantics, d_out, cells, b->ctx->stream);
+                e = hipStreamSynchronize(b->ctx->stream);
+                if (e == hipSuccess) e = hipMemcpy(directions, d_out, cells, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) st = fail(e, "unpack directions");
+                (void)hipFree(d_out);
+            }
+        }
+        if (h_matrix && st == ALN_OK) {
+            if (b->is_int) {
+                std::vector<int32_t> hi(cells);
+                hipError_t e = hipMemcpy(hi.data(), b->d_hmat, cells * 4, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) st = fail(e, "fetch H");
+                else for (uint64_t i = 0; i < cells; ++i) h_matrix[i] = (double)hi[i];
+            } else {
+                hipError_t e = hipMemcpy(h_matrix, b->d_hmat, cells * 8, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) st = fail(e, "fetch H");
+            }
+        }
+    }
+    batch_free(b);
+    return st != ALN_OK ? st : out->status;
+}

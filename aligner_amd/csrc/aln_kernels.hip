@@ -1,0 +1,525 @@
+// aln_kernels.hip -- gfx950 kernels of the DP matrix-fill + traceback path.
+//
+// What is computed (reference: aligner-core/src/simple/mod.rs:42-145 global, :168-264 local;
+// tie rules aligner-core/src/enums.rs:17-47; legacy twin src/align/aligner_core.rs:96-269):
+//   H[y][x] = max(H[y-1][x] - p, H[y][x-1] - p, H[y-1][x-1] + S[t[y-1]][q[x-1]])        (+ clamp at 0: legacy local)
+//   D[y][x] = Beginning if H==0 (local) else Top / Left / Diagonal in that tie order
+// with the reference's loop-carried penalty p (NOT Gotoh): see penalty<>() below.
+//
+// Mapping to the machine (CDNA4, wave64):
+//   * one wave owns a strip of up to 512 target rows; lane l owns R consecutive rows (register blocked);
+//   * the wave walks the query with an anti-diagonal skew: at step k lane l is at column x = k - l + 1, so the only
+//     cross-lane traffic per step is ONE DPP wave_shr:1 (lane l-1's bottom cell -> lane l's top input);
+//   * strip s+1 consumes the bottom row of strip s through a per-wave boundary row (HBM/L2 resident, read in
+//     64-column chunks and fed to lane 0 with v_readlane);
+//   * 2-bit directions are packed 16 per lane-register and stored 256 B per wave per block of steps (coalesced);
+//   * the local end cell is tracked per row in registers and reduced with DPP/shuffles at the end.
+// No MFMA: this is integer (or exact f64) max-plus DP.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+
+#include "aln_device.h"
+
+namespace {
+
+constexpr int D_TOP = 0, D_LEFT = 1, D_DIAG = 2, D_BEG = 3;
+
+// ---------------------------------------------------------------- score-type helpers
+template <typename SC> struct ScOps;
+
+template <> struct ScOps<int> {
+    static __device__ __forceinline__ bool eq(int m, int a) { return m == a; }
+    static __device__ __forceinline__ int vmax(int a, int b) { return a > b ? a : b; }
+    static __device__ __forceinline__ int lowest() { return INT_MIN; }
+    static __device__ __forceinline__ int shr1(int old, int v)
+    {   // lane l <- lane l-1; lane 0 keeps `old`  (DPP wave_shr:1, gfx9)
+        return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false);
+    }
+    static __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+    static __device__ __forceinline__ int xshfl(int v, int m) { return __shfl_xor(v, m); }
+    static __device__ __forceinline__ int from_double(double d) { return (int)d; }
+};
+
+template <> struct ScOps<double> {
+    // enums.rs:21-25: (max - x).abs() < f64::EPSILON
+    static __device__ __forceinline__ bool eq(double m, double a) { return fabs(m - a) < DBL_EPSILON; }
+    static __device__ __forceinline__ double vmax(double a, double b) { return fmax(a, b); }
+    static __device__ __forceinline__ double lowest() { return -DBL_MAX; }
+    static __device__ __forceinline__ double shr1(double old, double v)
+    {
+        int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
+        int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ double rdlane(double v, int l)
+    {
+        int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ double xshfl(double v, int m) { return __shfl_xor(v, m); }
+    static __device__ __forceinline__ double from_double(double d) { return d; }
+};
+
+template <int SEM> constexpr bool is_local() { return SEM == ALN_CORE_LOCAL || SEM == ALN_LEGACY_LOCAL; }
+template <int SEM> constexpr bool is_core() { return SEM == ALN_CORE_GLOBAL || SEM == ALN_CORE_LOCAL; }
+
+// H[0][x]: simple/mod.rs:59-62 + the overwritten corner :69 (legacy :104-107, :116-117)
+template <typename SC, int SEM>
+__device__ __forceinline__ SC border_top(uint32_t x, uint32_t N, SC del)
+{
+    if (is_local<SEM>() || x == 0) return (SC)0;
+    return x == N ? -((SC)N + (SC)1) * del : -(SC)x * del;
+}
+// H[y][0]: simple/mod.rs:64-67 + the overwritten corner :70 (legacy :109-115)
+template <typename SC, int SEM>
+__device__ __forceinline__ SC border_left(uint32_t y, uint32_t M, SC del)
+{
+    if (is_local<SEM>() || y == 0) return (SC)0;
+    return y == M ? -((SC)M + (SC)1) * del : -(SC)y * del;
+}
+
+// One cell.  topH/leftH/diagH are neighbour H values, p the carried penalty, s the substitution score.
+template <typename SC, int SEM>
+__device__ __forceinline__ void cell(SC topH, SC leftH, SC diagH, SC s, SC p, SC &h, int &d)
+{
+    using O = ScOps<SC>;
+    const SC a = topH - p, b = leftH - p, c = diagH + s;
+    SC m = O::vmax(O::vmax(a, b), c);
+    if (SEM == ALN_LEGACY_LOCAL) m = O::vmax(m, (SC)0);              // aligner_core.rs:210
+    int dd = O::eq(m, a) ? D_TOP : (O::eq(m, b) ? D_LEFT : D_DIAG);  // Top > Left > Diagonal
+    if (is_local<SEM>() && m == (SC)0) dd = D_BEG;                   // enums.rs:37 / aligner_core.rs:214
+    h = m;
+    d = dd;
+}
+
+// ---------------------------------------------------------------- per-wave state
+template <typename SC>
+struct Wave {
+    int lane;
+    uint32_t N, M;
+    const uint8_t *q, *t;
+    const SC *S;              // LDS copy of the substitution matrix, [t][q] contiguous
+    uint32_t cols;
+    SC del, ext;
+    uint32_t *dirw;           // this pair's direction region
+    SC *brow;                 // boundary row scratch (N + 66)
+    uint8_t *advice, *zrow;   // row-1 penalty advice / observed bottom-row zeros
+    SC *hmat;                 // optional H dump for this pair
+    bool hazard;
+    // running end-cell candidate of this lane (local semantics) and final corner value (global)
+    SC bv; uint32_t by, bx;
+    SC corner;
+};
+
+// a better-than-b for the local end cell
+template <typename SC, int SEM>
+__device__ __forceinline__ bool better(SC v, uint32_t y, uint32_t x, SC bv, uint32_t by, uint32_t bx)
+{
+    if (v > bv) return true;
+    if (v < bv) return false;
+    if (SEM == ALN_CORE_LOCAL)   // first maximum in row-major order (ndarray-stats argmax, simple/mod.rs:212)
+        return y < by || (y == by && x < bx);
+    // legacy: last `>=` in column-major visiting order (aligner_core.rs:224-228)
+    return x > bx || (x == bx && y > by);
+}
+
+// ---------------------------------------------------------------- one strip of rows, R rows per lane
+template <typename SC, int SEM, int R>
+__device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, const bool last)
+{
+    using O = ScOps<SC>;
+    constexpr int SPB = 16 / R;                       // steps per packed direction word
+    const int lane = w.lane;
+    const uint32_t N = w.N, M = w.M;
+    const uint32_t y0 = strip * ALN_STRIP_ROWS;
+    const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
+    const uint32_t L = (rows + R - 1) / R;            // lanes holding at least one valid row
+    const uint32_t nsteps = N + L - 1;
+    const uint32_t yb = y0 + (uint32_t)lane * R;      // this lane's rows are yb+1 .. yb+R
+    const uint32_t lb = (rows - 1) / R, rb = (rows - 1) % R;   // where the strip's last valid row lives
+    const SC del = w.del, ext = w.ext;
+
+    int tc[R];
+    SC Hl[R], rbv[R];
+    uint32_t rbx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t y = yb + 1 + r;
+        tc[r] = (y <= M) ? (int)w.t[y - 1] * (int)w.cols : 0;
+        Hl[r] = border_left<SC, SEM>(y, M, del);
+        rbv[r] = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : O::lowest();
+        rbx[r] = 0;
+    }
+    SC hdiag = border_left<SC, SEM>(yb, M, del);      // H[yb][0]
+    SC bottom = Hl[R - 1];
+    SC inchunk = (SC)0;
+    uint32_t advchunk = 0;
+
+    uint32_t *dirw = w.dirw + (strip * aln_strip_bytes(N)) / 4;
+    const uint32_t nkb = (nsteps + SPB - 1) / SPB;
+    for (uint32_t kb = 0; kb < nkb; ++kb) {
+        uint32_t dw = 0;
+#pragma unroll
+        for (int kk = 0; kk < SPB; ++kk) {
+            const uint32_t k = kb * SPB + kk;
+            if ((k & 63u) == 0) {                      // wave-uniform: next 64 columns of the incoming row
+                const uint32_t xi = k + 1 + lane;
+                if (strip > 0) inchunk = (xi <= N) ? w.brow[xi] : (SC)0;
+                if (SEM == ALN_CORE_LOCAL && strip == 0 && w.hazard) advchunk = (xi <= N) ? w.advice[xi] : 0u;
+            }
+            SC top0;
+            if (strip == 0) top0 = border_top<SC, SEM>(k + 1, N, del);
+            else top0 = O::rdlane(inchunk, (int)(k & 63u));
+            const SC topIn = O::shr1(top0, bottom);   // lane 0 <- top0, lane l <- lane l-1's bottom cell
+            const uint32_t xm1 = k - (uint32_t)lane;  // x - 1 (wraps for lanes that have not started)
+            if (xm1 < N) {
+                const uint32_t x = xm1 + 1;
+                const int qc = w.q[xm1];
+                SC top = topIn, diag = hdiag;
+                uint32_t dbits = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t y = yb + 1 + r;
+                    const SC s = w.S[tc[r] + qc];
+                    SC p;
+                    if (SEM == ALN_CORE_GLOBAL) {
+                        // penalty is `del` for the first visited cell only (simple/mod.rs:72,88-92)
+                        p = (r == 0 && y == 1 && x == 1) ? del : ext;
+                    } else if (SEM == ALN_CORE_LOCAL) {
+                        // carried penalty = del iff the previously visited cell was Beginning (H == 0):
+                        // the cell above for y >= 2; the BOTTOM cell of the previous column for y == 1 (advice)
+                        p = (top == (SC)0) ? del : ext;
+                        if (r == 0 && y == 1) {
+                            const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane((int)advchunk, (int)(k & 63u));
+                            p = (x == 1 || adv != 0) ? del : ext;
+                        }
+                    } else {
+                        p = del;
+                    }
+                    SC h;
+                    int d;
+                    cell<SC, SEM>(top, Hl[r], diag, s, p, h, d);
+                    diag = Hl[r];
+                    Hl[r] = h;
+                    top = h;
+                    dbits |= (uint32_t)d << (2 * r);
+                    if (is_local<SEM>()) {
+                        const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
+                        if (upd) { rbv[r] = h; rbx[r] = x; }
+                    }
+                    if (w.hmat != nullptr && y <= M) w.hmat[(size_t)y * (N + 1) + x] = h;
+                }
+                dw |= dbits << (kk * 2 * R);
+                hdiag = topIn;
+                bottom = Hl[R - 1];
+                if (!last && lane == 63) w.brow[x] = bottom;          // hand the bottom row to the next strip
+                if (SEM == ALN_CORE_LOCAL && last && w.hazard && (uint32_t)lane == lb) {
+                    SC hb = Hl[0];
+#pragma unroll
+                    for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Hl[r];
+                    w.zrow[x] = (hb == (SC)0) ? 1 : 0;
+                }
+            }
+        }
+        dirw[kb * 64 + lane] = dw;                     // 256 B per wave, coalesced
+    }
+
+    // fold this strip's per-row candidates into the lane's running end-cell candidate
+    if (is_local<SEM>()) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t y = yb + 1 + r;
+            if (y <= M && rbx[r] != 0 && better<SC, SEM>(rbv[r], y, rbx[r], w.bv, w.by, w.bx)) {
+                w.bv = rbv[r]; w.by = y; w.bx = rbx[r];
+            }
+        }
+    }
+    if (last) {                                        // H[M][N] lives in lane lb, row rb
+        SC hb = Hl[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Hl[r];
+        w.corner = O::rdlane(hb, (int)lb);
+    }
+}
+
+// ---------------------------------------------------------------- strict reference order, one lane
+// Exact for every input (it IS the reference's loop nest); used when the speculative fills do not converge
+// and on request (aln_params.force_serial).  Directions go to the row-major layout.
+template <typename SC, int SEM>
+__device__ __noinline__ void serial_fill(Wave<SC> &w)
+{
+    const uint32_t N = w.N, M = w.M;
+    const SC del = w.del, ext = w.ext;
+    SC *col = w.brow;                                  // H[.][x-1] on entry of column x, updated in place
+    uint8_t *dirs = reinterpret_cast<uint8_t *>(w.dirw);
+    const uint32_t rowbytes = (N + 4) / 4;
+    for (uint32_t y = 0; y <= M; ++y) col[y] = border_left<SC, SEM>(y, M, del);
+    SC p = del;
+    SC bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : ScOps<SC>::lowest();
+    uint32_t by = 0, bx = 0;
+    for (uint32_t x = 1; x <= N; ++x) {
+        const int qc = w.q[x - 1];
+        SC diag = col[0];
+        col[0] = border_top<SC, SEM>(x, N, del);
+        SC top = col[0];
+        for (uint32_t y = 1; y <= M; ++y) {
+            const SC left = col[y];
+            const SC s = w.S[(int)w.t[y - 1] * (int)w.cols + qc];
+            if (!is_core<SEM>()) p = del;
+            SC h;
+            int d;
+            cell<SC, SEM>(top, left, diag, s, p, h, d);
+            if (is_core<SEM>()) p = (d != D_BEG) ? ext : del;          // simple/mod.rs:88-92, :201-205
+            diag = left;
+            col[y] = h;
+            top = h;
+            uint8_t *bp = dirs + (size_t)y * rowbytes + (x >> 2);
+            const uint32_t sh = 2 * (x & 3u);
+            uint8_t old = (x == 1 || (x & 3u) == 0) ? 0 : *bp;
+            *bp = (uint8_t)(old | (d << sh));
+            if (is_local<SEM>() && better<SC, SEM>(h, y, x, bv, by, bx)) { bv = h; by = y; bx = x; }
+            if (w.hmat != nullptr) w.hmat[(size_t)y * (N + 1) + x] = h;
+        }
+    }
+    w.bv = bv; w.by = by; w.bx = bx;
+    w.corner = col[M];
+}
+
+template <typename SC, int SEM, int R>
+__device__ __forceinline__ void strip_call(Wave<SC> &w, uint32_t s, bool last) { run_strip<SC, SEM, R>(w, s, last); }
+
+template <typename SC, int SEM>
+__device__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair_result &res)
+{
+    using O = ScOps<SC>;
+    const int lane = w.lane;
+    const uint32_t N = desc.N, M = desc.M;
+    w.N = N; w.M = M;
+    w.q = a.seqs + desc.q_off;
+    w.t = a.seqs + desc.t_off;
+    w.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
+    w.hmat = a.hmat ? reinterpret_cast<SC *>(a.hmat) + desc.h_off : nullptr;
+    w.hazard = (SEM == ALN_CORE_LOCAL) && (w.del != w.ext) && N >= 2;
+    if (w.hmat != nullptr) {   // borders of the optional H dump (simple/mod.rs:55-70)
+        for (uint32_t x = lane; x <= N; x += 64) w.hmat[x] = border_top<SC, SEM>(x, N, w.del);
+        for (uint32_t y = lane; y <= M; y += 64) w.hmat[(size_t)y * (N + 1)] = border_left<SC, SEM>(y, M, w.del);
+    }
+    if (w.hazard)
+        for (uint32_t x = lane; x <= N + 1; x += 64) { w.advice[x] = 0; w.zrow[x] = 0; }
+
+    uint32_t passes = 0;
+    bool converged = false;
+    const uint32_t max_passes = a.max_passes ? a.max_passes : 4u;
+    if (!a.force_serial) {
+        const uint32_t ns = aln_num_strips(M);
+        do {
+            w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : O::lowest();
+            w.by = 0; w.bx = 0;
+            for (uint32_t s = 0; s < ns; ++s) {
+                const bool last = (s + 1 == ns);
+                const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8;
+                if (R == 8) strip_call<SC, SEM, 8>(w, s, last);
+                else if (R == 4) strip_call<SC, SEM, 4>(w, s, last);
+                else if (R == 2) strip_call<SC, SEM, 2>(w, s, last);
+                else strip_call<SC, SEM, 1>(w, s, last);
+            }
+            ++passes;
+            if (!w.hazard) { converged = true; break; }
+            // self-consistency: the advice used for row 1 must equal the bottom row this fill produced
+            __threadfence_block();
+            int mismatch = 0;
+            for (uint32_t x = 2 + lane; x <= N; x += 64) mismatch |= (w.advice[x] != w.zrow[x - 1]);
+            if (!__any(mismatch)) { converged = true; break; }
+            for (uint32_t x = 2 + lane; x <= N; x += 64) w.advice[x] = w.zrow[x - 1];
+            __threadfence_block();
+        } while (passes < max_passes);
+    }
+    uint32_t layout = ALN_LAYOUT_SKEW;
+    if (!converged) {
+        if (lane == 0) serial_fill<SC, SEM>(w);
+        __threadfence_block();
+        w.bv = O::rdlane(w.bv, 0);
+        w.by = __builtin_amdgcn_readlane((int)w.by, 0);
+        w.bx = __builtin_amdgcn_readlane((int)w.bx, 0);
+        w.corner = O::rdlane(w.corner, 0);
+        layout = ALN_LAYOUT_ROWMAJOR;
+        passes |= 0x80u;
+    } else if (is_local<SEM>()) {
+        // butterfly reduction of the per-lane candidates
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const SC ov = O::xshfl(w.bv, m);
+            const uint32_t oy = (uint32_t)__shfl_xor((int)w.by, m), ox = (uint32_t)__shfl_xor((int)w.bx, m);
+            if (ox != 0 && (w.bx == 0 || better<SC, SEM>(ov, oy, ox, w.bv, w.by, w.bx))) { w.bv = ov; w.by = oy; w.bx = ox; }
+        }
+    }
+    if (lane == 0) {
+        desc.layout = layout;
+        res.passes = passes;
+        res.flags = sizeof(SC) == 4 ? 1u : 0u;
+        res.start_y = res.start_x = 0;
+        res.aln_len = 0;
+        res.status = ALN_OK;
+        if (is_local<SEM>()) {
+            res.score = (double)w.bv;
+            res.f = (double)w.bv;
+            res.end_y = w.by; res.end_x = w.bx;
+            // core local: the argmax runs over the zero borders too; a non-positive maximum sits on (0,0)
+            if (SEM == ALN_CORE_LOCAL && !(w.bv > (SC)0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
+        } else {
+            res.score = (double)w.corner;
+            res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : (double)w.corner;   // simple/mod.rs:139
+            res.end_y = M; res.end_x = N;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- fill kernel: persistent waves over a work queue
+template <typename SC, int SEM>
+__global__ __launch_bounds__(256) void aln_fill_kernel(FillArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SC *S = reinterpret_cast<SC *>(smem);
+    const SC *gm = reinterpret_cast<const SC *>(a.matrix);
+    for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
+    __syncthreads();
+
+    Wave<SC> w;
+    w.lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint8_t *sc = a.scratch + (uint64_t)wave * a.scratch_stride;
+    const uint64_t brow_bytes = ((uint64_t)(a.max_len + 66) * sizeof(SC) + 63) & ~(uint64_t)63;
+    const uint64_t adv_bytes = ((uint64_t)a.max_len + 66 + 63) & ~(uint64_t)63;
+    w.brow = reinterpret_cast<SC *>(sc);
+    w.advice = sc + brow_bytes;
+    w.zrow = sc + brow_bytes + adv_bytes;
+    w.S = S;
+    w.cols = a.cols;
+    w.del = ScOps<SC>::from_double(a.del);
+    w.ext = ScOps<SC>::from_double(a.ext);
+
+    for (;;) {
+        uint32_t idx = 0;
+        if (w.lane == 0) idx = atomicAdd(a.counter, 1u);
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx >= a.n_pairs) break;
+        const uint32_t pair = a.order[idx];
+        PairDesc &desc = a.descs[pair];
+        aln_pair_result &res = a.results[pair];
+        if (desc.status != ALN_OK) {
+            if (w.lane == 0) {
+                res.f = 0.0; res.score = 0.0; res.end_y = res.end_x = res.start_y = res.start_x = 0;
+                res.aln_len = 0; res.status = desc.status; res.passes = 0; res.flags = 0;
+            }
+            continue;
+        }
+        do_pair<SC, SEM>(w, a, desc, res);
+    }
+}
+
+
+// ---------------------------------------------------------------- traceback
+// Direction of cell (y, x) from the packed store (borders are implicit: simple/mod.rs:55-67).
+__device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bool global, uint32_t y, uint32_t x)
+{
+    if (y == 0 || x == 0) {
+        if (!global || (y == 0 && x == 0)) return D_BEG;
+        return y == 0 ? D_LEFT : D_TOP;
+    }
+    const uint8_t *base = dirs + d.dir_off;
+    if (d.layout == ALN_LAYOUT_ROWMAJOR) {
+        const uint32_t rowbytes = (d.N + 4) / 4;
+        return (base[(size_t)y * rowbytes + (x >> 2)] >> (2 * (x & 3u))) & 3;
+    }
+    const uint32_t strip = (y - 1) / ALN_STRIP_ROWS;
+    const uint32_t ns = aln_num_strips(d.M);
+    const int R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8;
+    const uint32_t i = (y - 1) - strip * ALN_STRIP_ROWS;
+    const uint32_t lane = i / R, r = i % R;
+    const uint32_t k = (x - 1) + lane;
+    const uint32_t spb = 16 / R;
+    const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_strip_bytes(d.N));
+    const uint32_t word = wbase[(k / spb) * 64 + lane];
+    return (word >> (2 * ((k % spb) * R + r))) & 3;
+}
+
+// One thread per pair: the reference's pointer chase (simple/mod.rs:99-130, :213-245; legacy :146-176, :232-261),
+// including the duplicated seed pair.  Strings are written back to front, then reversed in place.
+extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs a)
+{
+    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= a.n_pairs) return;
+    const PairDesc &d = a.descs[pair];
+    aln_pair_result &res = a.results[pair];
+    if (res.status != ALN_OK) return;
+    const uint8_t *q = a.seqs + d.q_off, *t = a.seqs + d.t_off;
+    uint8_t *qa = a.tb + d.tb_off, *ta = qa + (d.N + d.M + 2);
+    const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
+    const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
+    uint32_t cy = res.end_y, cx = res.end_x;
+    qa[0] = q[cx - 1];
+    ta[0] = t[cy - 1];
+    if (legacy) { cy -= 1; cx -= 1; }   // legacy starts at the diagonal predecessor (aligner_core.rs:146-147, :232-233)
+    uint32_t len = 1;
+    for (;;) {
+        const int dd = dir_at(a.dirs, d, global, cy, cx);
+        if (dd == D_BEG) break;
+        if (dd == D_TOP) { qa[len] = a.blank; ta[len] = t[cy - 1]; cy--; }
+        else if (dd == D_LEFT) { qa[len] = q[cx - 1]; ta[len] = a.blank; cx--; }
+        else { qa[len] = q[cx - 1]; ta[len] = t[cy - 1]; cx--; cy--; }
+        len++;
+    }
+    for (uint32_t i = 0, j = len - 1; i < j; ++i, --j) {
+        uint8_t u = qa[i]; qa[i] = qa[j]; qa[j] = u;
+        u = ta[i]; ta[i] = ta[j]; ta[j] = u;
+    }
+    res.start_y = cy; res.start_x = cx;
+    res.aln_len = len;
+}
+
+// (M+1)x(N+1) Direction bytes for one pair = AlignmentResult.direction_matrix
+extern "C" __global__ void aln_unpack_directions_kernel(const uint8_t *dirs, const PairDesc *descs, uint32_t pair,
+                                                        int semantics, uint8_t *out)
+{
+    const PairDesc d = descs[pair];
+    const uint64_t total = (uint64_t)(d.M + 1) * (d.N + 1);
+    const bool global = (semantics == ALN_CORE_GLOBAL || semantics == ALN_LEGACY_GLOBAL);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t y = (uint32_t)(i / (d.N + 1)), x = (uint32_t)(i % (d.N + 1));
+        out[i] = (uint8_t)dir_at(dirs, d, global, y, x);
+    }
+}
+
+// ---------------------------------------------------------------- launch helpers used by aln_host.hip
+extern "C" void aln_launch_fill(const FillArgs *a, int is_int, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
+{
+    const dim3 g(grid), b(256);
+    if (is_int) {
+        switch (a->semantics) {
+        case ALN_CORE_GLOBAL: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_CORE_GLOBAL>), g, b, lds_bytes, s, *a); break;
+        case ALN_CORE_LOCAL: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_CORE_LOCAL>), g, b, lds_bytes, s, *a); break;
+        case ALN_LEGACY_GLOBAL: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_LEGACY_GLOBAL>), g, b, lds_bytes, s, *a); break;
+        default: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_LEGACY_LOCAL>), g, b, lds_bytes, s, *a); break;
+        }
+    } else {
+        if (a->semantics == ALN_CORE_GLOBAL) hipLaunchKernelGGL((aln_fill_kernel<double, ALN_CORE_GLOBAL>), g, b, lds_bytes, s, *a);
+        else hipLaunchKernelGGL((aln_fill_kernel<double, ALN_CORE_LOCAL>), g, b, lds_bytes, s, *a);
+    }
+}
+extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
+{
+    const uint32_t grid = (a->n_pairs + 63) / 64;
+    hipLaunchKernelGGL(aln_traceback_kernel, dim3(grid), dim3(64), 0, s, *a);
+}
+extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
+                                  uint64_t cells, hipStream_t s)
+{
+    uint32_t grid = (uint32_t)((cells + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(aln_unpack_directions_kernel, dim3(grid), dim3(256), 0, s, dirs, descs, pair, semantics, out);
+}

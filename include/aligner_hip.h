@@ -1,0 +1,130 @@
+/*
+ * aligner_hip.h -- C ABI of the MI355X-native DP matrix-fill + traceback path.
+ *
+ * This is the drop-in boundary for ONE hot path of ikramanop/aligner: the pairwise-alignment DP fill and
+ * traceback behind `AlignerTrait::perform_alignment` (aligner-core/src/lib.rs:27-40), implemented by
+ * `SimpleGlobalAligner` / `SimpleLocalAligner` (aligner-core/src/simple/mod.rs:42-145, :168-264) and by the
+ * legacy `SimpleAligner::{global,local}_alignment` (src/align/aligner_core.rs:96-183, :185-269).
+ * The reference has no FFI of its own; a thin Rust shim implements `AlignerTrait` for
+ * `Hip{Global,Local}Aligner<T>` on top of these entry points.  Plain pointers and sizes only; the library never
+ * frees caller memory and never returns owned pointers other than the opaque handles below.
+ *
+ * Conventions (same as the reference): query = columns (x, length N), target = rows (y, length M); the substitution
+ * lookup is matrix[[target_code, query_code]] (simple/mod.rs:85,198); residues are one byte holding the enum
+ * discriminant (`Into<usize>`, enums.rs:98-102,149-153); direction codes are the `Direction` discriminants
+ * Top=0, Left=1, Diagonal=2, Beginning=3 (enums.rs:9-15).
+ */
+#ifndef ALIGNER_HIP_H
+#define ALIGNER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALN_ABI_VERSION 1
+
+/* Which reference routine is reproduced bit-for-bit. */
+enum aln_semantics {
+    ALN_CORE_GLOBAL = 0,   /* SimpleGlobalAligner::perform_alignment   simple/mod.rs:42-145  */
+    ALN_CORE_LOCAL = 1,    /* SimpleLocalAligner::perform_alignment    simple/mod.rs:168-264 */
+    ALN_LEGACY_GLOBAL = 2, /* SimpleAligner::global_alignment          src/align/aligner_core.rs:96-183  */
+    ALN_LEGACY_LOCAL = 3   /* SimpleAligner::local_alignment           src/align/aligner_core.rs:185-269 */
+};
+
+/* Status codes.  1 mirrors `Err(Error::UnnecessaryArgument)` (lib.rs:51; simple/mod.rs:49-51,175-177).
+ * 2..4 are conditions on which the reference PANICS; a drop-in shim maps them back to panic!(). */
+enum aln_status {
+    ALN_OK = 0,
+    ALN_ERR_UNNECESSARY_ARGUMENT = 1,
+    ALN_ERR_EMPTY_SEQUENCE = 2,      /* last().unwrap() on an empty Vec      simple/mod.rs:103-104        */
+    ALN_ERR_CODE_OUT_OF_RANGE = 3,   /* ndarray index out of bounds          simple/mod.rs:85,198         */
+    ALN_ERR_NO_POSITIVE_CELL = 4,    /* argmax on a border -> usize underflow simple/mod.rs:214-215       */
+    ALN_ERR_DEVICE = 5,              /* HIP runtime / kernel failure (aln_last_error() has the text)      */
+    ALN_ERR_OOM = 6,
+    ALN_ERR_INVALID_ARGUMENT = 7,
+    ALN_ERR_UNSUPPORTED = 8
+};
+
+/* What the caller wants back (bitmask in aln_params.outputs). */
+enum aln_outputs {
+    ALN_OUT_SCORE = 1,       /* f / score / end cell */
+    ALN_OUT_TRACEBACK = 2,   /* aligned code strings, start cell, aln_len */
+    ALN_OUT_DIRECTIONS = 4,  /* (M+1)x(N+1) Direction bytes = AlignmentResult.direction_matrix (pair API only) */
+    ALN_OUT_H_MATRIX = 8     /* (M+1)x(N+1) f64 = AlignmentResult.alignment_matrix (pair API only, debug rate) */
+};
+
+/* Arguments of perform_alignment(del, ext, matrix, heuristics) + the output selection. */
+typedef struct aln_params {
+    int32_t semantics;          /* enum aln_semantics */
+    int32_t heuristics_present; /* Some(Heuristics) -> ALN_ERR_UNNECESSARY_ARGUMENT for the core semantics */
+    double del;                 /* gap opening ("deletions"); the single i32 gap cost for the legacy semantics */
+    double ext;                 /* gap extension; ignored by the legacy semantics */
+    const double *matrix;       /* host pointer, element [t][q] at matrix[t*row_stride + q] */
+    uint32_t rows, cols;        /* matrix shape; codes >= shape -> ALN_ERR_CODE_OUT_OF_RANGE */
+    int64_t row_stride;         /* in elements (ndarray stride of axis 0) */
+    uint32_t outputs;           /* bitmask of enum aln_outputs; 0 = SCORE|TRACEBACK */
+    uint8_t blank_code;         /* T::blank(): 98 for Protein and DNA (enums.rs:81,144) */
+    uint8_t force_f64;          /* 1: run the f64 kernels even if the inputs are integral (testing) */
+    uint8_t force_serial;       /* 1: run the strict reference-order kernel (one lane per pair; testing/fallback) */
+    uint8_t reserved0;
+    uint32_t max_passes;        /* CORE_LOCAL with del != ext: cap on speculative fills before the serial kernel; 0 = 4 */
+} aln_params;
+
+/* Fixed-size per-pair summary (48 bytes); also the record gathered across GPUs. */
+typedef struct aln_pair_result {
+    double f;                   /* Alignment.f: 0.0 for CORE_GLOBAL (simple/mod.rs:139), H max for local (:247) */
+    double score;               /* H[M][N] for the global semantics, H max for the local ones */
+    uint32_t end_y, end_x;      /* cell the traceback starts from (1-based matrix coordinates) */
+    uint32_t start_y, start_x;  /* cell where the traceback loop stopped */
+    uint32_t aln_len;           /* length of both aligned strings (includes the reference's duplicated seed pair) */
+    int32_t status;             /* enum aln_status for this pair */
+    uint32_t passes;            /* speculative fill passes used (1 unless CORE_LOCAL with del != ext); 0x80|n = serial fallback */
+    uint32_t flags;             /* bit0: integer kernels were used */
+} aln_pair_result;
+
+typedef struct aln_ctx aln_ctx;      /* one per process per GPU; thread-safe */
+typedef struct aln_batch aln_batch;  /* a batch of pairs staged in HBM */
+
+/* ---- context ---- */
+aln_ctx *aln_create(int device_id, int *status);
+void aln_destroy(aln_ctx *ctx);
+const char *aln_last_error(void);        /* thread-local text of the last ALN_ERR_DEVICE / _OOM */
+int aln_abi_version(void);
+int aln_device_info(aln_ctx *ctx, int *compute_units, size_t *hbm_bytes, char *name, size_t name_cap);
+
+/* ---- one pair, blocking (replaces one perform_alignment call).  q_aln / t_aln: capacity N+M+2 bytes each.
+ * directions: optional (M+1)*(N+1) bytes; h_matrix: optional (M+1)*(N+1) doubles. ---- */
+int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint8_t *query, size_t N, const uint8_t *target,
+                   size_t M, aln_pair_result *out, uint8_t *q_aln, uint8_t *t_aln, uint8_t *directions,
+                   double *h_matrix);
+
+/* ---- batch driver: semantics == map of aln_align_pair over independent pairs (the reference's only batch site is
+ * statistics/mod.rs:255-286).  Pair i: query = seqs[q_off[i] .. +q_len[i]), target = seqs[t_off[i] .. +t_len[i]).
+ * tb_buf (optional): pair i's aligned query at tb_off[i], aligned target at tb_off[i] + q_len[i] + t_len[i] + 2. ---- */
+int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
+                    const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
+                    aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off);
+
+/* ---- staged form of the batch driver: inputs resident in HBM, results left in HBM until fetched.
+ * create = validate + H2D + allocate; run = fill (+ exact re-fills) + traceback, asynchronous on `stream`
+ * (a hipStream_t passed as void*, NULL = the context's own stream); fetch = D2H. ---- */
+aln_batch *aln_batch_create(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
+                            const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
+                            int *status);
+int aln_batch_run(aln_batch *b, void *stream);
+int aln_batch_sync(aln_batch *b);
+int aln_batch_fetch(aln_batch *b, aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off);
+void aln_batch_destroy(aln_batch *b);
+uint64_t aln_batch_cells(const aln_batch *b);                 /* sum of M_i * N_i over valid pairs */
+size_t aln_batch_size(const aln_batch *b);
+void *aln_batch_results_device(aln_batch *b);                 /* device pointer: aln_pair_result[n_pairs] (for RCCL) */
+uint64_t aln_batch_direction_bytes(const aln_batch *b);       /* bytes of packed directions one run writes */
+/* kernel timing of the last run, from HIP events recorded on the launch stream (call after aln_batch_sync) */
+int aln_batch_timing(aln_batch *b, double *fill_ms, double *traceback_ms, uint32_t *fill_launches);
+void aln_batch_enable_timing(aln_batch *b, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNER_HIP_H */
