@@ -18,6 +18,8 @@
 
 #include "aln_device.h"
 
+#define ALN_TIMING_SLOTS 256u
+
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
@@ -60,8 +62,10 @@ struct aln_batch {
     void *d_hmat = nullptr;
     uint64_t hmat_elems = 0;
     hipStream_t last_stream = nullptr;
+    // timing ring: one event triple per run (fill start, fill end, traceback end), recorded on the launch stream
     bool timing = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev;
+    uint32_t ev_runs = 0;
     uint32_t fill_launches = 0;
 };
 
@@ -289,8 +293,10 @@ extern "C" void aln_batch_enable_timing(aln_batch *b, int on)
 {
     if (!b) return;
     b->timing = on != 0;
-    if (b->timing && !b->ev[0]) {
+    b->ev_runs = 0;
+    if (b->timing && b->ev.empty()) {
         (void)hipSetDevice(b->ctx->device);
+        b->ev.resize(3 * ALN_TIMING_SLOTS, nullptr);
         for (auto &e : b->ev) (void)hipEventCreate(&e);
     }
 }
@@ -311,11 +317,12 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
     fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
     fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[0], s));
+    hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
+    if (ev) HIPCHK(hipEventRecord(ev[0], s));
     aln_launch_fill(&fa, b->is_int ? 1 : 0, b->grid, b->lds_bytes, s);
     HIPCHK(hipGetLastError());
     b->fill_launches = 1;
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[1], s));
+    if (ev) HIPCHK(hipEventRecord(ev[1], s));
     const uint32_t outs = b->params.outputs ? b->params.outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
     if (outs & ALN_OUT_TRACEBACK) {
         TraceArgs ta{};
@@ -324,7 +331,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         aln_launch_traceback(&ta, s);
         HIPCHK(hipGetLastError());
     }
-    if (b->timing) HIPCHK(hipEventRecord(b->ev[2], s));
+    if (ev) { HIPCHK(hipEventRecord(ev[2], s)); b->ev_runs++; }
     return ALN_OK;
 }
 
@@ -338,13 +345,20 @@ extern "C" int aln_batch_sync(aln_batch *b)
 
 extern "C" int aln_batch_timing(aln_batch *b, double *fill_ms, double *tb_ms, uint32_t *fill_launches)
 {
-    if (!b || !b->timing || !b->ev[0]) return ALN_ERR_INVALID_ARGUMENT;
-    float f = 0, t = 0;
-    HIPCHK(hipEventSynchronize(b->ev[2]));
-    HIPCHK(hipEventElapsedTime(&f, b->ev[0], b->ev[1]));
-    HIPCHK(hipEventElapsedTime(&t, b->ev[1], b->ev[2]));
-    if (fill_ms) *fill_ms = f;
-    if (tb_ms) *tb_ms = t;
+    if (!b || !b->timing || b->ev.empty() || b->ev_runs == 0) return ALN_ERR_INVALID_ARGUMENT;
+    // mean over the runs recorded since aln_batch_enable_timing (at most the last ALN_TIMING_SLOTS)
+    const uint32_t runs = std::min<uint32_t>(b->ev_runs, ALN_TIMING_SLOTS);
+    double fs = 0, ts = 0;
+    for (uint32_t r = 0; r < runs; ++r) {
+        hipEvent_t *ev = &b->ev[3 * r];
+        float f = 0, t = 0;
+        HIPCHK(hipEventSynchronize(ev[2]));
+        HIPCHK(hipEventElapsedTime(&f, ev[0], ev[1]));
+        HIPCHK(hipEventElapsedTime(&t, ev[1], ev[2]));
+        fs += f; ts += t;
+    }
+    if (fill_ms) *fill_ms = fs / runs;
+    if (tb_ms) *tb_ms = ts / runs;
     if (fill_launches) *fill_launches = b->fill_launches;
     return ALN_OK;
 }

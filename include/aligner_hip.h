@@ -120,7 +120,8 @@ uint64_t aln_batch_cells(const aln_batch *b);                 /* sum of M_i * N_
 size_t aln_batch_size(const aln_batch *b);
 void *aln_batch_results_device(aln_batch *b);                 /* device pointer: aln_pair_result[n_pairs] (for RCCL) */
 uint64_t aln_batch_direction_bytes(const aln_batch *b);       /* bytes of packed directions one run writes */
-/* kernel timing of the last run, from HIP events recorded on the launch stream (call after aln_batch_sync) */
+/* mean kernel time per run since aln_batch_enable_timing(b, 1), from HIP events recorded on the launch stream
+ * around the fill kernel and the traceback kernel (last 256 runs; call after aln_batch_sync) */
 int aln_batch_timing(aln_batch *b, double *fill_ms, double *traceback_ms, uint32_t *fill_launches);
 void aln_batch_enable_timing(aln_batch *b, int on);
 

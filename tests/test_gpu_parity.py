@@ -1,0 +1,229 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+Bit-exact: integer scores, coordinates, every direction, both aligned strings.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from aligner_amd import _ffi, runtime, workloads
+from aligner_amd.batch import PairBatch, align_batch
+from aligner_amd.enums import DNA, Protein
+from aligner_amd.errors import AlignerError, ErrorKind, ReferencePanic
+from aligner_amd.legacy import SimpleAligner
+from aligner_amd.matrices import nucleotide_matrix
+from aligner_amd.simple import Heuristics, SimpleGlobalAligner, SimpleLocalAligner
+
+pytestmark = pytest.mark.gpu
+P = Protein.str_to_vec
+SEMS = [_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL, _ffi.LEGACY_GLOBAL, _ffi.LEGACY_LOCAL]
+
+
+def check_pair(orc, sem, q, t, dele, ext, S, full=True, **kw):
+    """GPU vs oracle on one pair: summary, strings and (optionally) the whole H and D matrices."""
+    ref = orc.align(sem, q, t, dele, ext, S, want_matrices=full)
+    if ref["status"] != 0:
+        with pytest.raises(ReferencePanic) as e:
+            runtime.align_pair(sem, q, t, dele, ext, S, **kw)
+        assert e.value.status == ref["status"]
+        return None
+    res, qa, ta, D, H = runtime.align_pair(sem, q, t, dele, ext, S, want_directions=full, want_h=full, **kw)
+    assert res.status == 0
+    assert res.score == ref["score"], (res.score, ref["score"])
+    assert res.f == ref["f"]
+    assert (res.end_y, res.end_x) == ref["end"]
+    assert (res.start_y, res.start_x) == ref["start"]
+    assert qa.tolist() == ref["qa"].tolist()
+    assert ta.tolist() == ref["ta"].tolist()
+    if full:
+        bad = np.argwhere(H != ref["H"])
+        assert len(bad) == 0, "H differs first at (y,x)=%s: gpu %s ref %s" % (bad[0], H[tuple(bad[0])], ref["H"][tuple(bad[0])])
+        bad = np.argwhere(D != ref["D"])
+        assert len(bad) == 0, "D differs first at (y,x)=%s" % (bad[0],)
+    return res
+
+
+def test_device_is_mi355x():
+    info = runtime.device_info()
+    assert info["compute_units"] >= 64
+    assert "gfx950" in info["name"], info
+
+
+# ---------------------------------------------------------------- the reference's own known answers
+def test_kat_legacy_global_on_gpu(kat):
+    """src/tests/test_alignment.rs:9-99 through SimpleAligner.global_alignment."""
+    r = SimpleAligner.from_seqs(b"HEAGAWGHEE", b"PAWHEAE---").global_alignment(8, kat["matrix"])
+    assert (r.get_alignment_matrix() == np.array(kat["global"]["H"])).all()
+    assert (r.get_direction_matrix() == np.array(kat["global"]["D"])).all()
+    assert r.get_optimal_alignment()[0].tolist() == kat["global"]["query_aligned"]
+    assert r.get_optimal_alignment()[1].tolist() == kat["global"]["target_aligned"]
+
+
+def test_kat_legacy_local_on_gpu(kat):
+    """src/tests/test_alignment.rs:101-191 through SimpleAligner.local_alignment."""
+    r = SimpleAligner.from_seqs(b"HEAGAWGHEE", b"PAWHEAE---").local_alignment(8, kat["matrix"])
+    assert (r.get_alignment_matrix() == np.array(kat["local"]["H"])).all()
+    assert (r.get_direction_matrix() == np.array(kat["local"]["D"])).all()
+    assert r.get_optimal_alignment()[0].tolist() == kat["local"]["query_aligned"]
+    assert r.get_optimal_alignment()[1].tolist() == kat["local"]["target_aligned"]
+    assert r.max_f == 28
+
+
+def test_kat_core_global_del_eq_ext(kat):
+    r = SimpleGlobalAligner.from_str_seqs("HEAGAWGHEE", "PAWHEAE").perform_alignment(8.0, 8.0, kat["matrix"],
+                                                                                     want_matrices=True)
+    assert (r.alignment_matrix == np.array(kat["global"]["H"], dtype=np.float64)).all()
+    assert (r.direction_matrix == np.array(kat["global"]["D"])).all()
+    assert r.alignment.query_str() == "HEAGAWGHE_EE" and r.alignment.target_str() == "_PA__W_HEAEE"
+    assert r.alignment.f == 0.0 and r.alignment.coords == ((1, 10), (1, 7))
+
+
+def test_cli_plumbing_book_example(blosum62):
+    """C1: aligner-cli defaults (del 11 / ext 2, BLOSUM62) on examples/book_example_1.fasta, both modes."""
+    g = SimpleGlobalAligner.from_str_seqs("HEAGAWGHEE", "PAWHEAE").perform_alignment(11.0, 2.0, blosum62)
+    assert (g.alignment.query_str(), g.alignment.target_str()) == ("HEAGAWGHE_EE", "P_A__W_HEAEE")
+    assert g.alignment.midline_str(blosum62) == "__A__W_HE_EE" and g.score == 21.0
+    l = SimpleLocalAligner.from_str_seqs("HEAGAWGHEE", "PAWHEAE").perform_alignment(11.0, 2.0, blosum62)
+    assert (l.alignment.query_str(), l.alignment.target_str()) == ("_AWGHE_EE", "PAW_HEAEE")
+    assert l.alignment.f == 27.0 and l.alignment.coords == ((5, 11), (1, 8))
+
+
+# ---------------------------------------------------------------- differential tests vs the oracle
+@pytest.mark.parametrize("sem", SEMS)
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (9, 1), (10, 7), (64, 64), (65, 63), (130, 129), (257, 70),
+                                   (200, 513), (90, 1030)])
+def test_random_protein_full_matrix(orc, blosum62, sem, shape):
+    N, M = shape
+    rng = np.random.default_rng(N * 1000 + M)
+    q = rng.integers(0, 20, N).astype(np.uint8)
+    t = rng.integers(0, 20, M).astype(np.uint8)
+    check_pair(orc, sem, q, t, 11, 2, blosum62)
+
+
+@pytest.mark.parametrize("sem", [_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL])
+@pytest.mark.parametrize("shape", [(33, 40), (150, 150), (300, 600)])
+def test_f64_kernels_match_oracle(orc, blosum62, sem, shape):
+    """f64 kernels: forced on integral data, and on a real-valued matrix (the heuristic aligner's input)."""
+    N, M = shape
+    rng = np.random.default_rng(7 + N)
+    q = rng.integers(0, 24, N).astype(np.uint8)
+    t = rng.integers(0, 24, M).astype(np.uint8)
+    res = check_pair(orc, sem, q, t, 11, 2, blosum62, force_f64=True)
+    assert res is None or (res.flags & 1) == 0
+    S = np.round(rng.normal(0, 2.5, (24, 24)), 3)
+    S[np.arange(24), np.arange(24)] = np.abs(S[np.arange(24), np.arange(24)]) + 2.0
+    res = check_pair(orc, sem, q, t, 3.7, 0.9, S)
+    assert res is None or (res.flags & 1) == 0
+
+
+@pytest.mark.parametrize("sem", SEMS)
+def test_serial_order_kernel(orc, blosum62, sem):
+    rng = np.random.default_rng(11)
+    q = rng.integers(0, 20, 77).astype(np.uint8)
+    t = rng.integers(0, 20, 140).astype(np.uint8)
+    res = check_pair(orc, sem, q, t, 11, 2, blosum62, force_serial=True)
+    assert res.passes & 0x80
+
+
+@pytest.mark.parametrize("gaps", [(2, 1), (3, 1), (1, 2), (11, 2)])
+@pytest.mark.parametrize("shape", [(200, 200), (200, 60), (300, 3), (257, 2), (64, 1), (500, 700)])
+def test_row1_hazard_zero_rich(orc, gaps, shape):
+    """CORE_LOCAL with del != ext: the penalty of cell (1,x) depends on the bottom cell of column x-1.
+    4-letter alphabet, +-1 scoring makes exact zeros (and bottom-row zeros) frequent; tiny M needs several passes."""
+    N, M = shape
+    rng = np.random.default_rng(N + 31 * M + gaps[0])
+    q = rng.integers(0, 4, N).astype(np.uint8)
+    t = rng.integers(0, 4, M).astype(np.uint8)
+    S = np.where(np.eye(4) > 0, 1.0, -1.0)
+    check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S)
+    check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S, max_passes=1)   # forces the serial fallback when needed
+
+
+def test_homopolymer_and_ties(orc, blosum62):
+    for q, t in ((np.zeros(300, np.uint8), np.zeros(280, np.uint8)),
+                 (np.tile(np.array([0, 1, 2, 3], np.uint8), 90), np.tile(np.array([0, 1, 2, 3], np.uint8), 70))):
+        for sem in SEMS:
+            check_pair(orc, sem, q, t, 11, 2, blosum62)
+            check_pair(orc, sem, q, t, 4, 4, blosum62)
+
+
+def test_c2_config_1k_pair(orc, blosum62):
+    """BASELINE C2: 1k x 1k protein, core local, 11/2 and 11/1, random and homolog variants; legacy local gap 11."""
+    for homolog in (False, True):
+        q, t = workloads.c2_pair(homolog)
+        for ext in (2, 1):
+            check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, ext, blosum62)
+        check_pair(orc, _ffi.LEGACY_LOCAL, q, t, 11, 11, blosum62)
+        check_pair(orc, _ffi.CORE_GLOBAL, q, t, 11, 2, blosum62, full=False)
+
+
+# ---------------------------------------------------------------- batch driver
+def _check_batch(orc, b, sem, dele, ext, S, **kw):
+    got = align_batch(b, sem, dele, ext, S, **kw)
+    ref, tb, tb_off = orc.align_batch(sem, b.seqs, b.q_off, b.q_len, b.t_off, b.t_len, dele, ext, S, n_threads=8)
+    for i in range(len(b)):
+        r, g = ref[i], got.results[i]
+        assert g["status"] == r.status, i
+        if r.status != 0:
+            continue
+        assert (g["score"], g["f"], g["end_y"], g["end_x"], g["start_y"], g["start_x"], g["aln_len"]) == \
+               (r.score, r.f, r.end_y, r.end_x, r.start_y, r.start_x, r.aln_len), i
+        cap = int(b.q_len[i] + b.t_len[i]) + 2
+        o = int(tb_off[i])
+        qa, ta = got.aligned(i)
+        assert (qa == tb[o:o + r.aln_len]).all() and (ta == tb[o + cap:o + cap + r.aln_len]).all(), i
+    return got
+
+
+def test_batch_mixed_protein(orc, blosum62):
+    b = workloads.c5_batch(n_pairs=300, lo=20, hi=700)
+    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    assert (got.results["flags"] & 1).all()
+    _check_batch(orc, b, _ffi.CORE_GLOBAL, 11, 2, blosum62)
+
+
+def test_batch_nucleotide_c3_shape(orc):
+    """BASELINE C3 shape at reduced count: 150 bp read pairs, core global, +5/-4, del 10 / ext 1."""
+    b = workloads.c3_batch(n_pairs=500)
+    _check_batch(orc, b, _ffi.CORE_GLOBAL, 10, 1, nucleotide_matrix())
+    _check_batch(orc, b, _ffi.CORE_LOCAL, 10, 1, nucleotide_matrix())
+
+
+def test_batch_with_invalid_pairs(orc, blosum62):
+    """Empty sequences and out-of-range codes are per-pair statuses; the rest of the batch is unaffected."""
+    rng = np.random.default_rng(3)
+    pairs = [(rng.integers(0, 20, 50).astype(np.uint8), rng.integers(0, 20, 60).astype(np.uint8)) for _ in range(6)]
+    pairs[1] = (np.zeros(0, np.uint8), pairs[1][1])
+    pairs[3] = (pairs[3][0], np.array([1, 2, 77, 3], np.uint8))
+    pairs[4] = (np.array([5], np.uint8), np.array([4], np.uint8))     # Q-C scores -3: no positive cell
+    b = PairBatch.from_pairs(pairs)
+    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    assert got.results["status"].tolist() == [0, _ffi.ERR_EMPTY_SEQUENCE, 0, _ffi.ERR_CODE_OUT_OF_RANGE,
+                                              _ffi.ERR_NO_POSITIVE_CELL, 0]
+
+
+# ---------------------------------------------------------------- error behaviour of the drop-in API
+def test_api_errors(blosum62):
+    with pytest.raises(AlignerError) as e:
+        SimpleLocalAligner.from_str_seqs("HEAG", "PAW").perform_alignment(11.0, 2.0, blosum62,
+                                                                           Heuristics(1.0, 1.0, np.ones(24)))
+    assert e.value.kind == ErrorKind.UnnecessaryArgument
+    with pytest.raises(AlignerError) as e:
+        SimpleLocalAligner.from_str_seqs("HEAG-", "PAW")
+    assert e.value.kind == ErrorKind.CharIsNotMatchable
+    with pytest.raises(ReferencePanic):
+        SimpleGlobalAligner.from_seqs([], [1, 2]).perform_alignment(11.0, 2.0, blosum62)
+    with pytest.raises(ReferencePanic):
+        SimpleLocalAligner.from_str_seqs("QQQ", "CCC").perform_alignment(11.0, 2.0, blosum62)
+
+
+def test_dna_alphabet_pair(orc):
+    a = SimpleLocalAligner.from_str_seqs("ATCGGATTACAGATTACA", "TTGATTACAGTTTACA", alphabet=DNA)
+    r = a.perform_alignment(10.0, 1.0, nucleotide_matrix())
+    ref = orc.align(orc.CORE_LOCAL, a.query, a.target, 10, 1, nucleotide_matrix())
+    assert r.alignment.f == ref["f"] and r.alignment.coords == ref["coords"]
+    assert r.alignment.query.tolist() == ref["qa"].tolist()
+
+
+# ---------------------------------------------------------------- full size (BASELINE C4)
+def test_c4_10k_pair_matches_oracle(orc, blosum62):
+    """10k x 10k protein, core local 11/2, homolog variant (long real alignment): score, coords, strings."""
+    q, t = workloads.c4_pair(homolog=True)
+    check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=False)

@@ -1,0 +1,140 @@
+"""Host-side logic that needs no GPU: alphabets, error surface, result post-processing, batch packing,
+the direction-region layout arithmetic, and that the C-ABI library loads and exports what the header declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from aligner_amd import _ffi, workloads
+from aligner_amd.alignment import Alignment
+from aligner_amd.batch import RESULT_DTYPE, PairBatch
+from aligner_amd.enums import ANY, BLANK, DNA, POS, Direction, Protein
+from aligner_amd.errors import AlignerError, ErrorKind
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_direction_discriminants():
+    # enums.rs:9-15 -- also the 2-bit code the kernels store
+    assert [int(d) for d in (Direction.Top, Direction.Left, Direction.Diagonal, Direction.Beginning)] == [0, 1, 2, 3]
+
+
+def test_protein_codec():
+    # enums.rs:56-84, :201-264
+    assert Protein.str_to_vec("ARNDCQEGHILKMFPSTWYVBJZX").tolist() == list(range(24))
+    assert Protein.str_to_vec("_+").tolist() == [BLANK, POS]
+    assert Protein.vec_to_str([0, 23, BLANK, POS, ANY, 57]) == "AX_+**"
+    assert Protein.volume() == 24 and Protein.blank() == 98 and Protein.pos() == 99
+    for bad in ("a", "-", " ", "O", "U", "*", "é"):
+        with pytest.raises(AlignerError) as e:
+            Protein.str_to_vec("AC" + bad)
+        assert e.value.kind == ErrorKind.CharIsNotMatchable
+    with pytest.raises(AlignerError):
+        Protein.from_u8_vec(b"AC-")          # enums.rs:292-303 errors
+    assert Protein.match_with_char("W") == 17 and Protein.convert_to_char(17) == "W"
+
+
+def test_dna_codec():
+    # enums.rs:139-147 A,T,C,G order; :454-467 from_u8_vec silently skips unknown bytes
+    assert DNA.str_to_vec("ATCG").tolist() == [0, 1, 2, 3]
+    assert DNA.volume() == 4
+    with pytest.raises(AlignerError):
+        DNA.str_to_vec("ATN")
+    assert DNA.from_u8_vec(b"AT NCG\n").tolist() == [0, 1, 2, 3]
+    codes, freqs = DNA.from_u8_vec_with_freqs(b"AATT-C")
+    assert codes.tolist() == [0, 0, 1, 1, 2] and np.allclose(freqs, [0.4, 0.4, 0.2, 0.0])
+
+
+def test_blosum62_as_embedded(blosum62):
+    """lib.rs:61-90 indexed by enum code: J/Z/X read NCBI's Z/X/* rows."""
+    c = Protein.match_with_char
+    assert blosum62.shape == (24, 24)
+    assert blosum62[c("W"), c("W")] == 11 and blosum62[c("A"), c("R")] == -1
+    assert blosum62[c("X"), c("X")] == 1 and blosum62[c("X"), c("A")] == -4       # the '*' row
+    assert blosum62[c("Z"), c("Z")] == -1                                          # NCBI's X row
+    assert blosum62[c("J"), c("J")] == 4 and blosum62[c("J"), c("E")] == 4         # NCBI's Z row
+
+
+def test_midline_and_frequency_matrix(orc, blosum62):
+    # alignment.rs:13-43, checked against the oracle's restatement
+    qa = Protein.str_to_vec("HEAGAWGHE_EE")
+    ta = Protein.str_to_vec("P_A__W_HEAEE")
+    a = Alignment(Protein, qa, ta, ((1, 10), (1, 7)), 0.0)
+    assert a.midline_str(blosum62) == "__A__W_HE_EE"
+    assert (a.get_alignment(blosum62) == orc.midline(qa, ta, blosum62)).all()
+    assert (a.get_frequency_matrix() == orc.frequency_matrix(qa, ta, 24)).all()
+    qa2, ta2 = Protein.str_to_vec("KR_W"), Protein.str_to_vec("RKAW")
+    assert Alignment(Protein, qa2, ta2, None, 0).midline_str(blosum62) == "++_W"   # K-R scores +2 -> Pos
+
+
+def test_pair_batch_packing():
+    rng = np.random.default_rng(0)
+    pairs = [(rng.integers(0, 20, n).astype(np.uint8), rng.integers(0, 20, m).astype(np.uint8))
+             for n, m in ((3, 5), (0, 2), (7, 1))]
+    b = PairBatch.from_pairs(pairs)
+    assert len(b) == 3 and b.cells == 15 + 0 + 7
+    for i, (q, t) in enumerate(pairs):
+        assert (b.query(i) == q).all() and (b.target(i) == t).all()
+    off, total = b.tb_layout()
+    assert off.tolist() == [0, 20, 28] and total == 20 + 8 + 20
+    sub = b.select([2, 0])
+    assert (sub.query(0) == pairs[2][0]).all() and (sub.target(1) == pairs[0][1]).all()
+
+
+def test_workload_generators_are_deterministic():
+    assert workloads.splitmix64(0, 3).tolist() == [16294208416658607535, 7960286522194355700, 487617019471545679]
+    a, b = workloads.c5_batch(n_pairs=50), workloads.c5_batch(n_pairs=50)
+    assert (a.seqs == b.seqs).all() and a.q_len.min() >= 200 and a.t_len.max() <= 2000
+    shard = workloads.c5_batch(n_pairs=50, indices=[7, 3])
+    assert (shard.query(0) == a.query(7)).all() and (shard.target(1) == a.target(3)).all()
+    ql, tl = workloads.c5_lengths()
+    assert abs(float((ql * tl).sum()) - 1.21e11) < 0.02e11            # E[cells] ~ 1.21e11
+    q, t = workloads.c2_pair(homolog=True)
+    assert len(q) == 1000 and 900 < len(t) < 1100
+    c3 = workloads.c3_batch(20)
+    assert set(c3.q_len.tolist()) == {150} and set(c3.t_len.tolist()) == {150} and c3.seqs.max() <= 3
+
+
+def test_result_record_layout_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "aligner_hip.h")).read()
+    body = hdr[hdr.index("typedef struct aln_pair_result {"):hdr.index("} aln_pair_result;")]
+    names = re.findall(r"(\w+)\s*(?:,|;)", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert names == [n for n in RESULT_DTYPE.names]
+    assert [f for f, _ in _ffi.PairResult._fields_] == list(RESULT_DTYPE.names)
+    assert C.sizeof(_ffi.PairResult) == RESULT_DTYPE.itemsize == 48
+
+
+def test_native_library_loads_and_exports_every_declared_symbol():
+    """No compute calls here (no GPU): the library must load and export exactly what include/aligner_hip.h declares."""
+    from aligner_amd import build as native_build
+    native_build.build()
+    lib = _ffi.load()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aligner_hip.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(aln_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(_ffi.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.aln_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(blosum62):
+    """Without a device the product path must raise; it must never produce an answer some other way."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from aligner_amd.errors import DeviceError
+    from aligner_amd.simple import SimpleLocalAligner
+    with pytest.raises(DeviceError):
+        SimpleLocalAligner.from_str_seqs("HEAGAWGHEE", "PAWHEAE").perform_alignment(11.0, 2.0, blosum62)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "aligner_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+                assert "aligner_oracle" not in src, f
