@@ -40,7 +40,7 @@ class Params(C.Structure):
     _fields_ = [("semantics", C.c_int32), ("heuristics_present", C.c_int32), ("del_", C.c_double),
                 ("ext", C.c_double), ("matrix", C.c_void_p), ("rows", C.c_uint32), ("cols", C.c_uint32),
                 ("row_stride", C.c_int64), ("outputs", C.c_uint32), ("blank_code", C.c_uint8),
-                ("force_f64", C.c_uint8), ("force_serial", C.c_uint8), ("reserved0", C.c_uint8),
+                ("force_f64", C.c_uint8), ("force_serial", C.c_uint8), ("force_generic", C.c_uint8),
                 ("max_passes", C.c_uint32)]
 
 

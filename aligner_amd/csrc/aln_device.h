@@ -9,8 +9,11 @@
 //               (R = 8 for every full strip; the last strip picks the smallest R in {1,2,4,8} covering its rows);
 //               lane l computes column x at wave step k = (x-1) + l (anti-diagonal skew);
 //               one u32 per lane holds R rows x (16/R) consecutive steps: word index = (k / SPB) * 64 + lane,
-//               SPB = 16/R, cell (row r, step k) at bits 2*((k % SPB)*R + r).  A wave therefore stores 256
-//               contiguous bytes per SPB steps -- fully coalesced, 0.25 B per cell.
+//               SPB = 16/R.  Cells are shifted in from the top (v_alignbit), so the cell of (row r, step k) sits
+//               at bits 30 - 2*((e - k)*R + (R-1-r)), e = last step of that block in which the lane is active
+//               (aln_dir_bitpos).  A wave therefore stores 256 contiguous bytes per SPB steps -- fully coalesced,
+//               0.25 B per cell.  The 2-bit value is the priority tag of the max: 0 Diagonal, 1 Left, 2 Top,
+//               3 Beginning (aln_tag_to_dir maps it to the reference's Direction discriminant).
 //             serial-order fallback (layout 1): plain row-major, row stride (N+4)/4 bytes, 4 cells per byte.
 //   results : aln_pair_result[n]
 //   tb      : aligned code strings, pair i at tb_off: query string then (M+N+2 bytes later) target string
@@ -46,6 +49,7 @@ struct FillArgs {
     uint64_t scratch_stride;  // bytes per wave
     uint32_t max_len;         // max over pairs of max(N, M): sizes the scratch arrays
     const void *matrix;       // device copy, contiguous rows x cols, int32 or double
+    uint32_t prof_stride;     // fast kernels: bytes of one wave's LDS query profile (cols * 512)
     uint32_t rows, cols;
     double del, ext;
     int32_t semantics;
@@ -66,6 +70,17 @@ struct TraceArgs {
     uint8_t blank;
 };
 
+// stored tag -> Direction discriminant (enums.rs:9-15: Top=0 Left=1 Diagonal=2 Beginning=3)
+__host__ __device__ inline int aln_tag_to_dir(int t) { return t == 3 ? 3 : 2 - t; }
+__host__ __device__ inline int aln_dir_to_tag(int d) { return d == 3 ? 3 : 2 - d; }
+// bit position of cell (row r of the lane, wave step k) inside its packed word; lane l is active for steps l .. l+N-1
+__host__ __device__ inline uint32_t aln_dir_bitpos(uint32_t k, uint32_t r, uint32_t lane, uint32_t N, int R)
+{
+    const uint32_t spb = 16u / (uint32_t)R;
+    const uint32_t bend = (k / spb) * spb + spb - 1, lend = lane + N - 1;
+    const uint32_t e = bend < lend ? bend : lend;
+    return 30u - 2u * ((e - k) * (uint32_t)R + ((uint32_t)R - 1u - r));
+}
 // rows handled per lane in the strip that starts `rem` rows before the end of the target
 __host__ __device__ inline int aln_pick_r(uint32_t rem)
 {

@@ -20,7 +20,7 @@
 
 #define ALN_TIMING_SLOTS 256u
 
-extern "C" void aln_launch_fill(const FillArgs *a, int is_int, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
+extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s);
@@ -41,6 +41,8 @@ struct aln_batch {
     aln_params params{};
     size_t n = 0;
     bool is_int = true;
+    bool fast = false;        // integer kernels with the LDS query profile + packed max3 keys
+    uint32_t prof_stride = 0;
     uint64_t cells = 0;
     uint64_t dir_bytes = 0;
     uint64_t tb_bytes = 0;
@@ -225,6 +227,11 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     // integer kernels are exact iff every value is integral and |H| cannot leave i32
     b->is_int = all_int && !p->force_f64 && maxabs * (double)max_span < 1073741824.0;
     if (!core && !b->is_int) { g_err = "legacy scores overflow i32 for these lengths"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
+    // fast integer kernels: keys are 4*H + tag in i32 and the profile holds 4*s - 1 as int8
+    double smin = 0, smax = 0;
+    for (double v : md) { smin = std::min(smin, v); smax = std::max(smax, v); }
+    b->fast = b->is_int && !want_h && !p->force_serial && !p->force_generic && cols <= 64 && smin >= -31.0 && smax <= 32.0 &&
+              maxabs * (double)max_span < 268435456.0;
 
     // ---- LPT order: largest pairs first into the device work queue
     std::vector<uint32_t> order(n);
@@ -240,7 +247,8 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
     b->scratch_stride = brow_bytes + 2 * adv_bytes;
-    b->lds_bytes = (uint32_t)((uint64_t)rows * cols * sc_size);
+    b->lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
+    if (b->fast) { b->prof_stride = cols * 512u; b->lds_bytes += 4u * b->prof_stride; }
 
     // ---- device allocations + H2D
     uint64_t seq_bytes = 0;
@@ -313,13 +321,13 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     fa.seqs = b->d_seqs; fa.descs = b->d_descs; fa.order = b->d_order; fa.n_pairs = (uint32_t)b->n;
     fa.counter = b->d_counter; fa.dirs = b->d_dirs; fa.results = b->d_results;
     fa.scratch = b->d_scratch; fa.scratch_stride = b->scratch_stride; fa.max_len = b->max_len;
-    fa.matrix = b->d_matrix; fa.rows = b->params.rows; fa.cols = b->params.cols;
+    fa.matrix = b->d_matrix; fa.rows = b->params.rows; fa.cols = b->params.cols; fa.prof_stride = b->prof_stride;
     fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
     fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
     fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
     hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], s));
-    aln_launch_fill(&fa, b->is_int ? 1 : 0, b->grid, b->lds_bytes, s);
+    aln_launch_fill(&fa, b->is_int ? 1 : 0, b->fast ? 1 : 0, b->grid, b->lds_bytes, s);
     HIPCHK(hipGetLastError());
     b->fill_launches = 1;
     if (ev) HIPCHK(hipEventRecord(ev[1], s));

@@ -112,6 +112,9 @@ struct Wave {
     // running end-cell candidate of this lane (local semantics) and final corner value (global)
     SC bv; uint32_t by, bx;
     SC corner;
+    // fast integer path only
+    uint8_t *prof;            // LDS: this wave's query profile, cols x 512 bytes
+    int nd4, ne4;             // -4*del, -4*ext
 };
 
 // a better-than-b for the local end cell
@@ -174,12 +177,14 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
             if (strip == 0) top0 = border_top<SC, SEM>(k + 1, N, del);
             else top0 = O::rdlane(inchunk, (int)(k & 63u));
             const SC topIn = O::shr1(top0, bottom);   // lane 0 <- top0, lane l <- lane l-1's bottom cell
+            // cross-lane read kept in wave-uniform control flow (see FastStrip::step)
+            const uint32_t adv = (SEM == ALN_CORE_LOCAL && strip == 0)
+                                     ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, (int)(k & 63u)) : 0u;
             const uint32_t xm1 = k - (uint32_t)lane;  // x - 1 (wraps for lanes that have not started)
             if (xm1 < N) {
                 const uint32_t x = xm1 + 1;
                 const int qc = w.q[xm1];
                 SC top = topIn, diag = hdiag;
-                uint32_t dbits = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t y = yb + 1 + r;
@@ -192,10 +197,7 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
                         // carried penalty = del iff the previously visited cell was Beginning (H == 0):
                         // the cell above for y >= 2; the BOTTOM cell of the previous column for y == 1 (advice)
                         p = (top == (SC)0) ? del : ext;
-                        if (r == 0 && y == 1) {
-                            const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane((int)advchunk, (int)(k & 63u));
-                            p = (x == 1 || adv != 0) ? del : ext;
-                        }
+                        if (r == 0 && y == 1) p = (x == 1 || adv != 0) ? del : ext;
                     } else {
                         p = del;
                     }
@@ -205,14 +207,13 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
                     diag = Hl[r];
                     Hl[r] = h;
                     top = h;
-                    dbits |= (uint32_t)d << (2 * r);
+                    dw = (dw >> 2) | ((uint32_t)aln_dir_to_tag(d) << 30);   // same packing as v_alignbit in the fast path
                     if (is_local<SEM>()) {
                         const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
                         if (upd) { rbv[r] = h; rbx[r] = x; }
                     }
                     if (w.hmat != nullptr && y <= M) w.hmat[(size_t)y * (N + 1) + x] = h;
                 }
-                dw |= dbits << (kk * 2 * R);
                 hdiag = topIn;
                 bottom = Hl[R - 1];
                 if (!last && lane == 63) w.brow[x] = bottom;          // hand the bottom row to the next strip
@@ -288,10 +289,205 @@ __device__ __noinline__ void serial_fill(Wave<SC> &w)
     w.corner = col[M];
 }
 
-template <typename SC, int SEM, int R>
-__device__ __forceinline__ void strip_call(Wave<SC> &w, uint32_t s, bool last) { run_strip<SC, SEM, R>(w, s, last); }
+// ================================================================= fast integer path
+// Same recurrence, reformulated so that one v_max3 yields value AND direction:
+//   carried state  L = 4*H + 1                      (H exact in the upper 30 bits)
+//   Top  key = Ltop  + 1 - 4p   (tag 2)     Left key = Lleft - 4p (tag 1)     Diag key = Ldiag + (4s - 1) (tag 0)
+//   key = max3(...)  ->  H' = key >> 2,  tag = key & 3 in the reference's tie order Top > Left > Diagonal;
+//   L' = (key & ~3) | 1.   Beginning (H' == 0, local) is tag 3; the legacy clamp at zero is max(key, 3).
+// The substitution scores come from a per-strip query profile in LDS:  P[c][row] = 4*S[t[row]][c] - 1 as int8, so one
+// ds_read of R bytes per step feeds the lane's R cells; the query code travels down the lanes with the same
+// DPP wave_shr:1 that carries the boundary cell.  ~9 VALU ops per cell + ~3 for the local end-cell tracking.
+template <int R> struct ProfWord;
+template <> struct ProfWord<8> { using T = uint2; };
+template <> struct ProfWord<4> { using T = uint32_t; };
+template <> struct ProfWord<2> { using T = uint16_t; };
+template <> struct ProfWord<1> { using T = uint8_t; };
 
-template <typename SC, int SEM>
+template <int R>
+__device__ __forceinline__ int prof_byte(const typename ProfWord<R>::T &pw, int r)
+{
+    if constexpr (R == 8) return (int)(int8_t)(((r < 4 ? pw.x : pw.y) >> (8 * (r & 3))) & 0xff);
+    else return (int)(int8_t)(((uint32_t)pw >> (8 * r)) & 0xff);
+}
+
+__device__ __forceinline__ int shr1_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
+
+template <int SEM, int R>
+struct FastStrip {
+    static constexpr int SPB = 16 / R;
+    using PW = typename ProfWord<R>::T;
+    Wave<int> &w;
+    const uint32_t strip;
+    const bool last, first;
+    const int lane;
+    const uint32_t N;
+    uint32_t lb, rb;
+    int Ll[R], rbv[R];
+    uint32_t rbx[R];
+    int hdiag, bottom, qoff, inchunk, qchunk;
+    uint32_t advchunk, dw;
+    PW pw;
+    const uint8_t *prow;       // this lane's column of the profile: prof + lane*R
+    int nd4, ne4;
+
+    __device__ __forceinline__ FastStrip(Wave<int> &w_, uint32_t s, bool l)
+        : w(w_), strip(s), last(l), first(s == 0), lane(w_.lane), N(w_.N) {}
+
+    template <bool MASKED>
+    __device__ __forceinline__ void step(const uint32_t k)
+    {
+        if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
+            const uint32_t xi = k + (uint32_t)lane;             // 0-based column
+            if (!first) inchunk = (xi < N) ? w.brow[xi + 1] : 1;
+            if (SEM == ALN_CORE_LOCAL && first && w.hazard) advchunk = (xi < N) ? w.advice[xi + 1] : 0u;
+            qchunk = (xi + 1 < N) ? (int)w.q[xi + 1] * (64 * R) : 0;
+        }
+        const int sel = (int)(k & 63u);
+        int top0;
+        if (first) top0 = is_local<SEM>() ? 1 : ((k + 1 == N) ? 1 + (int)(N + 1) * nd4 : 1 + (int)(k + 1) * nd4);
+        else top0 = __builtin_amdgcn_readlane(inchunk, sel);
+        const int topIn = shr1_i(top0, bottom);                 // lane 0 <- row above the strip, lane l <- lane l-1
+        // cross-lane reads stay in wave-uniform control flow: inside a divergent branch the compiler may compute
+        // their operand for the active lanes only
+        const uint32_t adv = (SEM == ALN_CORE_LOCAL && first) ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, sel) : 0u;
+        const PW pwc = pw;                                      // profile bytes of THIS step (loaded one step ago)
+        qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);   // next step's query code reaches every lane
+        pw = *reinterpret_cast<const PW *>(prow + qoff);
+        const uint32_t xm1 = k - (uint32_t)lane;
+        if (!MASKED || xm1 < N) {
+            const uint32_t x = xm1 + 1;
+            int top = topIn, diag = hdiag;
+            bool zr = (topIn == 1);                             // "cell above is Beginning" -> penalty del
+            if (SEM == ALN_CORE_LOCAL && first && lane == 0) {
+                // row 1: the carried penalty comes from the bottom cell of the previous column (advice)
+                zr = (k == 0) || (adv != 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int negp;
+                if (SEM == ALN_CORE_LOCAL) negp = zr ? nd4 : ne4;
+                else if (SEM == ALN_CORE_GLOBAL) negp = (r == 0 && first && lane == 0 && k == 0) ? nd4 : ne4;
+                else negp = nd4;
+                const int a = top + 1 + negp;
+                const int b = Ll[r] + negp;
+                const int c = diag + prof_byte<R>(pwc, r);
+                int key = max(max(a, b), c);
+                if (SEM == ALN_LEGACY_LOCAL) key = max(key, 3);
+                const int nl = (key & ~3) | 1;
+                int stored = key;
+                if (SEM == ALN_CORE_LOCAL) { zr = (nl == 1); stored = zr ? 3 : key; }
+                dw = __builtin_amdgcn_alignbit((uint32_t)stored, dw, 2);
+                if (is_local<SEM>()) {
+                    const bool upd = (SEM == ALN_CORE_LOCAL) ? (nl > rbv[r]) : (nl >= rbv[r]);
+                    if (upd) { rbv[r] = nl; rbx[r] = x; }
+                }
+                diag = Ll[r];
+                Ll[r] = nl;
+                top = nl;
+            }
+            hdiag = topIn;
+            bottom = Ll[R - 1];
+            if (!last && lane == 63) w.brow[x] = bottom;
+            if (SEM == ALN_CORE_LOCAL && last && w.hazard && (uint32_t)lane == lb) {
+                int hb = Ll[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Ll[r];
+                w.zrow[x] = (hb == 1) ? 1 : 0;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void run()
+    {
+        const uint32_t M = w.M;
+        const uint32_t y0 = strip * ALN_STRIP_ROWS;
+        const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
+        const uint32_t L = (rows + R - 1) / R;
+        const uint32_t nsteps = N + L - 1;
+        const uint32_t yb = y0 + (uint32_t)lane * R;
+        lb = (rows - 1) / R; rb = (rows - 1) % R;
+        nd4 = w.nd4; ne4 = w.ne4;
+        prow = w.prof + lane * R;
+
+        // ---- query profile of this strip's rows: P[c][row] = 4*S[t[row]][c] - 1  (int8), row-contiguous per code
+        int tc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t y = yb + 1 + r;
+            tc[r] = (y <= M) ? (int)w.t[y - 1] * (int)w.cols : 0;
+            // left border H[y][0] in L form (simple/mod.rs:64-70)
+            Ll[r] = is_local<SEM>() ? 1 : (y == M ? 1 + (int)(M + 1) * nd4 : 1 + (int)y * nd4);
+            rbv[r] = (SEM == ALN_LEGACY_LOCAL) ? -3 : INT_MIN;
+            rbx[r] = 0;
+        }
+        for (uint32_t c = 0; c < w.cols; ++c) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t bte = (uint32_t)(4 * w.S[tc[r] + c] - 1) & 0xffu;
+                if (r < 4) lo |= bte << (8 * r); else hi |= bte << (8 * (r - 4));
+            }
+            uint8_t *dst = w.prof + c * (64 * R) + lane * R;
+            if constexpr (R == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+            else if constexpr (R == 4) *reinterpret_cast<uint32_t *>(dst) = lo;
+            else if constexpr (R == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)lo;
+            else *dst = (uint8_t)lo;
+        }
+        hdiag = is_local<SEM>() || yb == 0 ? 1 : 1 + (int)yb * nd4;     // H[yb][0]; yb < M always for valid lanes
+        bottom = Ll[R - 1];
+        inchunk = 1; qchunk = 0; advchunk = 0; dw = 0;
+        qoff = (lane == 0) ? (int)w.q[0] * (64 * R) : 0;
+        pw = *reinterpret_cast<const PW *>(prow + qoff);
+
+        uint32_t *dirw = w.dirw + (strip * aln_strip_bytes(N)) / 4;
+        const uint32_t nkb = (nsteps + SPB - 1) / SPB;
+        // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
+        const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
+        const uint32_t kb_steady1 = max(kb_steady0, min(nkb, N / SPB));
+        uint32_t kb = 0;
+        for (; kb < kb_steady0; ++kb) {
+#pragma unroll
+            for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
+            dirw[kb * 64 + lane] = dw;
+        }
+        for (; kb < kb_steady1; ++kb) {
+#pragma unroll
+            for (int kk = 0; kk < SPB; ++kk) step<false>(kb * SPB + kk);
+            dirw[kb * 64 + lane] = dw;
+        }
+        for (; kb < nkb; ++kb) {
+#pragma unroll
+            for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
+            dirw[kb * 64 + lane] = dw;
+        }
+
+        if (is_local<SEM>()) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t y = yb + 1 + r;
+                if (y <= M && rbx[r] != 0 && better<int, SEM>(rbv[r], y, rbx[r], w.bv, w.by, w.bx)) {
+                    w.bv = rbv[r]; w.by = y; w.bx = rbx[r];
+                }
+            }
+        }
+        if (last) {
+            int hb = Ll[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Ll[r];
+            w.corner = __builtin_amdgcn_readlane(hb, (int)lb);
+        }
+    }
+};
+
+template <typename SC, int SEM, int R, bool FAST>
+__device__ __forceinline__ void strip_call(Wave<SC> &w, uint32_t s, bool last)
+{
+    if constexpr (FAST) { FastStrip<SEM, R> fs(w, s, last); fs.run(); }
+    else run_strip<SC, SEM, R>(w, s, last);
+}
+
+template <typename SC, int SEM, bool FAST>
 __device__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair_result &res)
 {
     using O = ScOps<SC>;
@@ -309,6 +505,9 @@ __device__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair
     }
     if (w.hazard)
         for (uint32_t x = lane; x <= N + 1; x += 64) { w.advice[x] = 0; w.zrow[x] = 0; }
+    // lanes exchange advice / boundary rows through the wave's scratch: make the stores above (and those of the
+    // previous pair) visible before any lane loads them (s_waitcnt vmcnt(0); same-CU L1 is coherent)
+    __threadfence_block();
 
     uint32_t passes = 0;
     bool converged = false;
@@ -316,15 +515,16 @@ __device__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair
     if (!a.force_serial) {
         const uint32_t ns = aln_num_strips(M);
         do {
-            w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : O::lowest();
+            w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)(FAST ? -3 : -1) : O::lowest();
             w.by = 0; w.bx = 0;
             for (uint32_t s = 0; s < ns; ++s) {
                 const bool last = (s + 1 == ns);
+                if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
                 const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8;
-                if (R == 8) strip_call<SC, SEM, 8>(w, s, last);
-                else if (R == 4) strip_call<SC, SEM, 4>(w, s, last);
-                else if (R == 2) strip_call<SC, SEM, 2>(w, s, last);
-                else strip_call<SC, SEM, 1>(w, s, last);
+                if (R == 8) strip_call<SC, SEM, 8, FAST>(w, s, last);
+                else if (R == 4) strip_call<SC, SEM, 4, FAST>(w, s, last);
+                else if (R == 2) strip_call<SC, SEM, 2, FAST>(w, s, last);
+                else strip_call<SC, SEM, 1, FAST>(w, s, last);
             }
             ++passes;
             if (!w.hazard) { converged = true; break; }
@@ -356,6 +556,10 @@ __device__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair
             if (ox != 0 && (w.bx == 0 || better<SC, SEM>(ov, oy, ox, w.bv, w.by, w.bx))) { w.bv = ov; w.by = oy; w.bx = ox; }
         }
     }
+    if (FAST && converged) {      // fast path carries L = 4*H + 1
+        w.bv = (SC)((int)w.bv >> 2);
+        w.corner = (SC)((int)w.corner >> 2);
+    }
     if (lane == 0) {
         desc.layout = layout;
         res.passes = passes;
@@ -380,7 +584,7 @@ __device__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair
 }  // namespace
 
 // ---------------------------------------------------------------- fill kernel: persistent waves over a work queue
-template <typename SC, int SEM>
+template <typename SC, int SEM, bool FAST>
 __global__ __launch_bounds__(256) void aln_fill_kernel(FillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -402,6 +606,10 @@ __global__ __launch_bounds__(256) void aln_fill_kernel(FillArgs a)
     w.cols = a.cols;
     w.del = ScOps<SC>::from_double(a.del);
     w.ext = ScOps<SC>::from_double(a.ext);
+    const uint32_t mat_bytes = (a.rows * a.cols * (uint32_t)sizeof(SC) + 15u) & ~15u;
+    w.prof = smem + mat_bytes + (threadIdx.x >> 6) * a.prof_stride;
+    w.nd4 = -4 * (int)a.del;
+    w.ne4 = -4 * (int)a.ext;
 
     for (;;) {
         uint32_t idx = 0;
@@ -418,7 +626,7 @@ __global__ __launch_bounds__(256) void aln_fill_kernel(FillArgs a)
             }
             continue;
         }
-        do_pair<SC, SEM>(w, a, desc, res);
+        do_pair<SC, SEM, FAST>(w, a, desc, res);
     }
 }
 
@@ -445,7 +653,7 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
     const uint32_t spb = 16 / R;
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_strip_bytes(d.N));
     const uint32_t word = wbase[(k / spb) * 64 + lane];
-    return (word >> (2 * ((k % spb) * R + r))) & 3;
+    return aln_tag_to_dir((int)((word >> aln_dir_bitpos(k, r, lane, d.N, R)) & 3u));
 }
 
 // One thread per pair: the reference's pointer chase (simple/mod.rs:99-130, :213-245; legacy :146-176, :232-261),
@@ -496,20 +704,29 @@ extern "C" __global__ void aln_unpack_directions_kernel(const uint8_t *dirs, con
 }
 
 // ---------------------------------------------------------------- launch helpers used by aln_host.hip
-extern "C" void aln_launch_fill(const FillArgs *a, int is_int, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
+extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), b(256);
-    if (is_int) {
+#define ALN_LAUNCH(SC, SEM, FAST) hipLaunchKernelGGL((aln_fill_kernel<SC, SEM, FAST>), g, b, lds_bytes, s, *a)
+    if (is_int && fast) {
         switch (a->semantics) {
-        case ALN_CORE_GLOBAL: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_CORE_GLOBAL>), g, b, lds_bytes, s, *a); break;
-        case ALN_CORE_LOCAL: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_CORE_LOCAL>), g, b, lds_bytes, s, *a); break;
-        case ALN_LEGACY_GLOBAL: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_LEGACY_GLOBAL>), g, b, lds_bytes, s, *a); break;
-        default: hipLaunchKernelGGL((aln_fill_kernel<int, ALN_LEGACY_LOCAL>), g, b, lds_bytes, s, *a); break;
+        case ALN_CORE_GLOBAL: ALN_LAUNCH(int, ALN_CORE_GLOBAL, true); break;
+        case ALN_CORE_LOCAL: ALN_LAUNCH(int, ALN_CORE_LOCAL, true); break;
+        case ALN_LEGACY_GLOBAL: ALN_LAUNCH(int, ALN_LEGACY_GLOBAL, true); break;
+        default: ALN_LAUNCH(int, ALN_LEGACY_LOCAL, true); break;
+        }
+    } else if (is_int) {
+        switch (a->semantics) {
+        case ALN_CORE_GLOBAL: ALN_LAUNCH(int, ALN_CORE_GLOBAL, false); break;
+        case ALN_CORE_LOCAL: ALN_LAUNCH(int, ALN_CORE_LOCAL, false); break;
+        case ALN_LEGACY_GLOBAL: ALN_LAUNCH(int, ALN_LEGACY_GLOBAL, false); break;
+        default: ALN_LAUNCH(int, ALN_LEGACY_LOCAL, false); break;
         }
     } else {
-        if (a->semantics == ALN_CORE_GLOBAL) hipLaunchKernelGGL((aln_fill_kernel<double, ALN_CORE_GLOBAL>), g, b, lds_bytes, s, *a);
-        else hipLaunchKernelGGL((aln_fill_kernel<double, ALN_CORE_LOCAL>), g, b, lds_bytes, s, *a);
+        if (a->semantics == ALN_CORE_GLOBAL) ALN_LAUNCH(double, ALN_CORE_GLOBAL, false);
+        else ALN_LAUNCH(double, ALN_CORE_LOCAL, false);
     }
+#undef ALN_LAUNCH
 }
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
 {

@@ -64,7 +64,7 @@ def raise_for_status(st, where=""):
 
 
 def make_params(semantics, del_, ext, matrix, heuristics_present=False, outputs=0, blank=98, force_f64=False,
-                force_serial=False, max_passes=0):
+                force_serial=False, force_generic=False, max_passes=0):
     """Returns (Params, keepalive).  `matrix` is the caller's Array2<f64>: any 2-D float array, any row stride."""
     m = np.asarray(matrix, dtype=np.float64)
     if m.ndim != 2:
@@ -73,7 +73,7 @@ def make_params(semantics, del_, ext, matrix, heuristics_present=False, outputs=
         m = np.ascontiguousarray(m)
     p = _ffi.Params(int(semantics), int(bool(heuristics_present)), float(del_), float(ext), m.ctypes.data,
                     m.shape[0], m.shape[1], m.strides[0] // 8, int(outputs), int(blank), int(bool(force_f64)),
-                    int(bool(force_serial)), 0, int(max_passes))
+                    int(bool(force_serial)), int(bool(force_generic)), int(max_passes))
     return p, m
 
 

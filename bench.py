@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the DP matrix-fill + traceback path on N MI355X GPUs of one node.
+
+A "step" is one pass of the hot path (fill kernel + exact re-fills + traceback kernel [+ RCCL gather of the 48-byte
+summaries when N > 1]) over one batch of synthetic pairs that is already resident in HBM.
+
+Workload (BASELINE.json configs[4], "C5"): 100 000 protein pairs, both lengths iid uniform in [200, 2000],
+core local semantics (SimpleLocalAligner), BLOSUM62, del 11 / ext 2.  The batch is fixed; with N > 1 the pairs are
+sharded over the ranks by balanced cells (LPT), so scaling is STRONG (total work fixed), as north_star asks
+("scaling at 8 GPUs on a 100k-pair batch").  `--pairs` shrinks the batch for quick runs.
+At N = 1 the line also carries the single-pair configuration (configs[3], 10k x 10k) as "single_pair".
+
+Launch: `python bench.py` (N=1) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured-achievable)
+ALG_BYTES_PER_CELL = 0.25      # one 2-bit direction per cell is the only per-cell datum that must leave the chip
+
+
+def cpu_baseline(batch, S, target_seconds=15.0):
+    """Times the CPU oracle (the reference's algorithm and memory behaviour, oracle/aligner_oracle.c) on a bounded
+    sample of the SAME workload, all host cores, static pair partitioning (statistics/mod.rs:255-286 style)."""
+    import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 64))
+    # calibrate on a few pairs, then size the sample for ~target_seconds
+    cal = batch.select(range(min(len(batch), threads)))
+    t0 = time.perf_counter()
+    oracle.align_batch(oracle.CORE_LOCAL, cal.seqs, cal.q_off, cal.q_len, cal.t_off, cal.t_len, 11, 2, S, threads)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    rate = cal.cells / dt
+    want_cells = rate * target_seconds
+    n = int(min(len(batch), max(threads, want_cells / max(batch.cells / len(batch), 1))))
+    sample = batch.select(range(n))
+    t0 = time.perf_counter()
+    oracle.align_batch(oracle.CORE_LOCAL, sample.seqs, sample.q_off, sample.q_len, sample.t_off, sample.t_len, 11, 2,
+                       S, threads)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample.cells / dt / 1e9, 4), "unit": "GCUPS", "cores": threads, "kind": "port",
+            "sample": "first %d of the batch's pairs (%.3g cells), fill+argmax+traceback, %.1f s wall" % (
+                n, sample.cells, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=100000, help="size of the C5 batch (default: the full 100 000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from aligner_amd import _ffi, runtime, workloads
+    from aligner_amd.batch import RESULT_DTYPE, PairBatch, StagedBatch
+    from aligner_amd.distributed import SummaryGather, device_bytes_as_tensor, lpt_shards
+    from aligner_amd.matrices import get_blosum62
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    n_gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    S = get_blosum62()
+    # ---- the batch and this rank's shard (every rank derives the same partition from the lengths alone)
+    qlen, tlen = workloads.c5_lengths(args.pairs)
+    cells_all = qlen * tlen
+    shards = lpt_shards(cells_all, world)
+    mine = shards[rank]
+    batch = workloads.c5_batch(args.pairs, indices=mine)
+    total_cells = int(cells_all.sum())
+
+    outs = _ffi.OUT_SCORE | _ffi.OUT_TRACEBACK
+    sb = StagedBatch(batch, _ffi.CORE_LOCAL, 11, 2, S, device=local_rank, outputs=outs)
+    stream = torch.cuda.Stream()
+    rec = RESULT_DTYPE.itemsize
+    if world > 1:
+        gather = SummaryGather([len(s) for s in shards], rank, "cuda")
+        view = device_bytes_as_tensor(sb.results_device_ptr, len(batch) * rec)
+
+    def step():
+        with torch.cuda.stream(stream):
+            sb.run(stream.cuda_stream)
+            if world > 1:
+                gather(view)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    sb.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    timing = sb.timing()
+    sb.enable_timing(False)
+
+    # ---- light integrity check outside the timed region: every pair finished OK, gathered records are the shard's
+    res = sb.fetch(want_traceback=False).results
+    ok = int((res["status"] == 0).sum())
+    refills = int((res["passes"] > 1).sum())
+    if world > 1:
+        everyone = gather.unpack(shards, args.pairs)
+        assert (everyone[mine] == res).all() and int((everyone["status"] == 0).sum()) >= ok
+
+    line = None
+    if rank == 0:
+        gcups = total_cells * args.steps / elapsed / 1e9
+        fill_s = timing["fill_ms"] / 1e3
+        alg_bytes = ALG_BYTES_PER_CELL * batch.cells + float((batch.q_len + batch.t_len).sum()) + 48.0 * len(batch)
+        achieved = alg_bytes / fill_s / 1e9
+        traffic = None
+        try:
+            with open(args.traffic_json) as f:
+                tj = json.load(f)
+            key = "c5_%d_n%d" % (args.pairs, world)
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+        line = {
+            "metric": "GCUPS (DP cell updates/s), fill + traceback, bit-exact vs CPU ref",
+            "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "C5: %d protein pairs, lengths iid U[200,2000], core local (SimpleLocalAligner), "
+                                   "BLOSUM62, del 11 / ext 2, seed 0xA11C0005" % args.pairs,
+                       "pairs": args.pairs, "cells": total_cells, "sharding": "LPT by cells over %d rank(s)" % world,
+                       "pairs_ok_rank0": ok, "pairs_refilled_rank0": refills},
+            "roofline": {"bound": "hbm", "kernel": "aln_fill_kernel<int, CORE_LOCAL>",
+                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": round(timing["fill_ms"], 4),
+                         "traceback_ms": round(timing["traceback_ms"], 4),
+                         "fill_only_gcups_rank0": round(batch.cells / fill_s / 1e9, 3),
+                         "valu_frac": round(batch.cells / fill_s * 16 / 78.6e12, 5)},
+        }
+
+    # ---- N = 1 extras: the single-pair configuration and the CPU baseline
+    if rank == 0 and world == 1:
+        if not args.no_single_pair:
+            q, t = workloads.c4_pair(homolog=False)
+            one = PairBatch.from_pairs([(q, t)])
+            sp = StagedBatch(one, _ffi.CORE_LOCAL, 11, 2, S, device=local_rank, outputs=outs)
+            with torch.cuda.stream(stream):
+                sp.run(stream.cuda_stream)
+            torch.cuda.synchronize()
+            sp.enable_timing(True)
+            t0 = time.perf_counter()
+            reps = 3
+            with torch.cuda.stream(stream):
+                for _ in range(reps):
+                    sp.run(stream.cuda_stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            tm = sp.timing()
+            r1 = sp.fetch(want_traceback=False).results[0]
+            line["single_pair"] = {"workload": "C4: one 10000 x 10000 protein pair, core local, BLOSUM62, 11/2",
+                                   "gcups": round(one.cells / dt / 1e9, 3), "ms": round(dt * 1e3, 3),
+                                   "fill_ms": round(tm["fill_ms"], 3), "traceback_ms": round(tm["traceback_ms"], 3),
+                                   "fill_only_gcups": round(one.cells / tm["fill_ms"] / 1e6, 3),
+                                   "score": float(r1["score"]), "status": int(r1["status"])}
+            sp.close()
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch, S)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    sb.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,7 +67,7 @@ typedef struct aln_params {
     uint8_t blank_code;         /* T::blank(): 98 for Protein and DNA (enums.rs:81,144) */
     uint8_t force_f64;          /* 1: run the f64 kernels even if the inputs are integral (testing) */
     uint8_t force_serial;       /* 1: run the strict reference-order kernel (one lane per pair; testing/fallback) */
-    uint8_t reserved0;
+    uint8_t force_generic;      /* 1: run the generic (non-profiled) integer kernels (testing) */
     uint32_t max_passes;        /* CORE_LOCAL with del != ext: cap on speculative fills before the serial kernel; 0 = 4 */
 } aln_params;
 

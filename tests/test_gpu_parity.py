@@ -16,15 +16,17 @@ P = Protein.str_to_vec
 SEMS = [_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL, _ffi.LEGACY_GLOBAL, _ffi.LEGACY_LOCAL]
 
 
-def check_pair(orc, sem, q, t, dele, ext, S, full=True, **kw):
-    """GPU vs oracle on one pair: summary, strings and (optionally) the whole H and D matrices."""
+def check_pair(orc, sem, q, t, dele, ext, S, full=True, directions_only=False, **kw):
+    """GPU vs oracle on one pair: summary, strings and (optionally) the whole H and D matrices.
+    directions_only: compare D but do not request H (the H dump is served by the generic kernels only)."""
     ref = orc.align(sem, q, t, dele, ext, S, want_matrices=full)
     if ref["status"] != 0:
         with pytest.raises(ReferencePanic) as e:
             runtime.align_pair(sem, q, t, dele, ext, S, **kw)
         assert e.value.status == ref["status"]
         return None
-    res, qa, ta, D, H = runtime.align_pair(sem, q, t, dele, ext, S, want_directions=full, want_h=full, **kw)
+    res, qa, ta, D, H = runtime.align_pair(sem, q, t, dele, ext, S, want_directions=full,
+                                           want_h=full and not directions_only, **kw)
     assert res.status == 0
     assert res.score == ref["score"], (res.score, ref["score"])
     assert res.f == ref["f"]
@@ -33,8 +35,9 @@ def check_pair(orc, sem, q, t, dele, ext, S, full=True, **kw):
     assert qa.tolist() == ref["qa"].tolist()
     assert ta.tolist() == ref["ta"].tolist()
     if full:
-        bad = np.argwhere(H != ref["H"])
-        assert len(bad) == 0, "H differs first at (y,x)=%s: gpu %s ref %s" % (bad[0], H[tuple(bad[0])], ref["H"][tuple(bad[0])])
+        if H is not None:
+            bad = np.argwhere(H != ref["H"])
+            assert len(bad) == 0, "H differs first at (y,x)=%s: gpu %s ref %s" % (bad[0], H[tuple(bad[0])], ref["H"][tuple(bad[0])])
         bad = np.argwhere(D != ref["D"])
         assert len(bad) == 0, "D differs first at (y,x)=%s" % (bad[0],)
     return res
@@ -90,11 +93,15 @@ def test_cli_plumbing_book_example(blosum62):
 @pytest.mark.parametrize("shape", [(1, 1), (1, 7), (9, 1), (10, 7), (64, 64), (65, 63), (130, 129), (257, 70),
                                    (200, 513), (90, 1030)])
 def test_random_protein_full_matrix(orc, blosum62, sem, shape):
+    """Full H and D matrices from the generic integer kernels (the H dump routes there), summary + directions +
+    strings from the fast (query-profile) integer kernels."""
     N, M = shape
     rng = np.random.default_rng(N * 1000 + M)
     q = rng.integers(0, 20, N).astype(np.uint8)
     t = rng.integers(0, 20, M).astype(np.uint8)
     check_pair(orc, sem, q, t, 11, 2, blosum62)
+    check_pair(orc, sem, q, t, 11, 2, blosum62, directions_only=True)
+    check_pair(orc, sem, q, t, 11, 2, blosum62, directions_only=True, force_generic=True)
 
 
 @pytest.mark.parametrize("sem", [_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL])
@@ -133,7 +140,9 @@ def test_row1_hazard_zero_rich(orc, gaps, shape):
     t = rng.integers(0, 4, M).astype(np.uint8)
     S = np.where(np.eye(4) > 0, 1.0, -1.0)
     check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S)
+    check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S, directions_only=True)
     check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S, max_passes=1)   # forces the serial fallback when needed
+    check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S, directions_only=True, max_passes=1)
 
 
 def test_homopolymer_and_ties(orc, blosum62):
@@ -142,6 +151,8 @@ def test_homopolymer_and_ties(orc, blosum62):
         for sem in SEMS:
             check_pair(orc, sem, q, t, 11, 2, blosum62)
             check_pair(orc, sem, q, t, 4, 4, blosum62)
+            check_pair(orc, sem, q, t, 11, 2, blosum62, directions_only=True)
+            check_pair(orc, sem, q, t, 4, 4, blosum62, directions_only=True)
 
 
 def test_c2_config_1k_pair(orc, blosum62):
@@ -150,7 +161,11 @@ def test_c2_config_1k_pair(orc, blosum62):
         q, t = workloads.c2_pair(homolog)
         for ext in (2, 1):
             check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, ext, blosum62)
+            check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, ext, blosum62, directions_only=True)
         check_pair(orc, _ffi.LEGACY_LOCAL, q, t, 11, 11, blosum62)
+        check_pair(orc, _ffi.LEGACY_LOCAL, q, t, 11, 11, blosum62, directions_only=True)
+        check_pair(orc, _ffi.LEGACY_GLOBAL, q, t, 11, 11, blosum62, directions_only=True)
+        check_pair(orc, _ffi.CORE_GLOBAL, q, t, 11, 2, blosum62, directions_only=True)
         check_pair(orc, _ffi.CORE_GLOBAL, q, t, 11, 2, blosum62, full=False)
 
 
