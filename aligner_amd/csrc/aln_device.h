@@ -24,8 +24,9 @@
 #include "../../include/aligner_hip.h"
 
 #define ALN_STRIP_ROWS 512      // rows per full strip (64 lanes x R=8)
-#define ALN_LAYOUT_SKEW 0u
-#define ALN_LAYOUT_ROWMAJOR 1u
+#define ALN_LAYOUT_SKEW 0u      // 512-row strips, R = 8 except the last strip (batch kernels)
+#define ALN_LAYOUT_ROWMAJOR 1u  // serial-order fallback
+#define ALN_LAYOUT_UNIFORM 2u   // every strip has 64*R rows, R in bits 8..15 (single-pair kernel)
 
 struct PairDesc {
     uint64_t q_off, t_off;   // into seqs
@@ -57,6 +58,26 @@ struct FillArgs {
     uint32_t force_serial;
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
     uint8_t blank;
+};
+
+// one large pair, one wave per strip, strips pipelined through granule rows in HBM/L2
+struct SingleArgs {
+    const uint8_t *seqs;
+    PairDesc *descs;
+    uint32_t pair;
+    uint8_t *dirs;
+    aln_pair_result *results;
+    uint64_t *granules;       // ns rows of gstride granules, zeroed before every pass
+    uint64_t gstride;
+    uint8_t *advice, *zrow;   // N + 66 bytes each
+    int32_t *cand;            // per strip: {bv (L form), by, bx, corner (L form)}
+    uint32_t *ctrl;           // [0] abort, [1 + p] "pass p is needed", [15] "serial fallback needed"
+    const void *matrix;
+    uint32_t rows, cols;
+    double del, ext;
+    int32_t semantics;
+    uint32_t R, ns, pass, max_passes;
+    uint32_t hazard;
 };
 
 struct TraceArgs {

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -22,6 +23,8 @@
 
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
+extern "C" void aln_launch_single(const SingleArgs *a, uint32_t lds_bytes, int with_serial, hipStream_t s);
+extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s);
 
@@ -63,6 +66,16 @@ struct aln_batch {
     void *d_matrix = nullptr;
     void *d_hmat = nullptr;
     uint64_t hmat_elems = 0;
+    // pairs routed to the single-pair (one wave per strip) kernel, processed one after another
+    std::vector<uint32_t> single_pairs;
+    std::vector<uint32_t> single_r;
+    size_t n_small = 0;
+    uint64_t *d_granules = nullptr;
+    uint64_t granule_bytes = 0;
+    uint8_t *d_advice1 = nullptr;
+    int32_t *d_cand = nullptr;
+    uint32_t *d_ctrl = nullptr;
+    uint32_t single_max_n = 0;
     hipStream_t last_stream = nullptr;
     // timing ring: one event triple per run (fill start, fill end, traceback end), recorded on the launch stream
     bool timing = false;
@@ -144,7 +157,7 @@ static void batch_free(aln_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     void *ptrs[] = {b->d_seqs, b->d_descs, b->d_order, b->d_counter, b->d_dirs, b->d_results, b->d_tb, b->d_scratch,
-                    b->d_matrix, b->d_hmat};
+                    b->d_matrix, b->d_hmat, b->d_granules, b->d_advice1, b->d_cand, b->d_ctrl};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -189,9 +202,9 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     if (!core && !all_int) { g_err = "legacy semantics are i32: del and matrix must be integral"; batch_free(b); return ALN_ERR_INVALID_ARGUMENT; }
     if (!core && p->force_f64) { g_err = "legacy semantics have no f64 form"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
 
-    // ---- per-pair validation + layout
+    // ---- per-pair validation
     b->descs.resize(n);
-    uint64_t dir_total = 0, tb_total = 0, hm_total = 0, cells = 0;
+    uint64_t cells = 0;
     uint32_t max_len = 1;
     uint64_t max_span = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -210,20 +223,12 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
             for (uint32_t k = 0; k < d.M && d.status == ALN_OK; ++k) if (t[k] >= rows) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
         }
         if (d.status != ALN_OK) continue;
-        d.dir_off = dir_total;
-        dir_total += aln_dir_bytes(d.N, d.M);
-        d.tb_off = tb_total;
-        tb_total += 2ull * ((uint64_t)d.N + d.M + 2);
-        if (want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
         cells += (uint64_t)d.N * d.M;
         max_len = std::max(max_len, std::max(d.N, d.M));
         max_span = std::max(max_span, (uint64_t)d.N + d.M + 2);
     }
     b->cells = cells;
-    b->dir_bytes = dir_total;
-    b->tb_bytes = tb_total;
     b->max_len = max_len;
-    b->hmat_elems = hm_total;
     // integer kernels are exact iff every value is integral and |H| cannot leave i32
     b->is_int = all_int && !p->force_f64 && maxabs * (double)max_span < 1073741824.0;
     if (!core && !b->is_int) { g_err = "legacy scores overflow i32 for these lengths"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
@@ -233,15 +238,57 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     b->fast = b->is_int && !want_h && !p->force_serial && !p->force_generic && cols <= 64 && smin >= -31.0 && smax <= 32.0 &&
               maxabs * (double)max_span < 268435456.0;
 
+    // ---- routing + HBM layout.  A pair goes to the single-pair kernel (one wave per strip, strips pipelined across
+    // CUs) when it is large, or when the batch is too small to fill the chip with one wave per pair.
+    uint64_t dir_total = 0, tb_total = 0, hm_total = 0;
+    const char *env_r = getenv("ALN_SINGLE_R");
+    const char *env_off = getenv("ALN_NO_SINGLE");
+    for (size_t i = 0; i < n; ++i) {
+        PairDesc &d = b->descs[i];
+        if (d.status != ALN_OK) continue;
+        const uint64_t pc = (uint64_t)d.N * d.M;
+        bool single = b->fast && !env_off && d.N >= 64 && d.M >= 128 && (pc >= (1ull << 24) || (n <= 16 && pc >= (1ull << 18)));
+        uint64_t dbytes = aln_dir_bytes(d.N, d.M);
+        if (single) {
+            uint32_t R = env_r ? (uint32_t)atoi(env_r) : (d.M > 4096 ? 2u : 1u);
+            if (R != 1 && R != 2 && R != 4 && R != 8) R = 2;
+            while ((d.M + 64 * R - 1) / (64 * R) > 4096 && R < 8) R *= 2;      // keep every strip's wave resident
+            if ((d.M + 64 * R - 1) / (64 * R) > 4096) single = false;
+            if (single) {
+                const uint32_t ns = (d.M + 64 * R - 1) / (64 * R), spb = 16 / R;
+                dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * ((d.N + 63 + spb - 1) / spb) * 256u);
+                b->single_pairs.push_back((uint32_t)i);
+                b->single_r.push_back(R);
+                const uint64_t gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
+                b->granule_bytes = std::max<uint64_t>(b->granule_bytes, std::max<uint64_t>((uint64_t)ns * gstride * 8, 4ull * (d.M + 2)));
+                b->single_max_n = std::max(b->single_max_n, std::max(d.N, ns));
+            }
+        }
+        d.dir_off = dir_total;
+        dir_total += dbytes;
+        d.tb_off = tb_total;
+        tb_total += 2ull * ((uint64_t)d.N + d.M + 2);
+        if (want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
+    }
+    b->dir_bytes = dir_total;
+    b->tb_bytes = tb_total;
+    b->hmat_elems = hm_total;
+
     // ---- LPT order: largest pairs first into the device work queue
-    std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    {
+        std::vector<char> is_single(n, 0);
+        for (uint32_t i : b->single_pairs) is_single[i] = 1;
+        for (size_t i = 0; i < n; ++i) if (!is_single[i]) order.push_back((uint32_t)i);
+    }
+    b->n_small = order.size();
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
         return (uint64_t)b->descs[a].N * b->descs[a].M > (uint64_t)b->descs[c].N * b->descs[c].M;
     });
 
     // ---- grid: persistent waves, 4 per workgroup
-    const uint32_t wg_needed = (uint32_t)((n + 3) / 4);
+    const uint32_t wg_needed = (uint32_t)((b->n_small + 3) / 4);
     b->grid = std::max(1u, std::min(wg_needed, (uint32_t)ctx->cus * 4u));
     const uint64_t sc_size = b->is_int ? 4 : 8;
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
@@ -269,10 +316,16 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     BCHK(dmalloc((void **)&b->d_scratch, (uint64_t)b->grid * 4 * b->scratch_stride));
     BCHK(dmalloc((void **)&b->d_matrix, (uint64_t)rows * cols * sc_size));
     if (want_h) BCHK(dmalloc((void **)&b->d_hmat, hm_total * sc_size));
+    if (!b->single_pairs.empty()) {
+        BCHK(dmalloc((void **)&b->d_granules, b->granule_bytes));
+        BCHK(dmalloc((void **)&b->d_advice1, 2ull * (b->single_max_n + 128)));
+        BCHK(dmalloc((void **)&b->d_cand, 16ull * (b->single_max_n + 64)));
+        BCHK(dmalloc((void **)&b->d_ctrl, 256));
+    }
     if (n) {
         BCHK(hipMemcpy(b->d_seqs, seqs, seq_bytes, hipMemcpyHostToDevice));
         BCHK(hipMemcpy(b->d_descs, b->descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice));
-        BCHK(hipMemcpy(b->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!order.empty()) BCHK(hipMemcpy(b->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (b->is_int) {
         std::vector<int32_t> mi(md.size());
@@ -318,7 +371,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     if (b->n == 0) return ALN_OK;
     HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, s));
     FillArgs fa{};
-    fa.seqs = b->d_seqs; fa.descs = b->d_descs; fa.order = b->d_order; fa.n_pairs = (uint32_t)b->n;
+    fa.seqs = b->d_seqs; fa.descs = b->d_descs; fa.order = b->d_order; fa.n_pairs = (uint32_t)b->n_small;
     fa.counter = b->d_counter; fa.dirs = b->d_dirs; fa.results = b->d_results;
     fa.scratch = b->d_scratch; fa.scratch_stride = b->scratch_stride; fa.max_len = b->max_len;
     fa.matrix = b->d_matrix; fa.rows = b->params.rows; fa.cols = b->params.cols; fa.prof_stride = b->prof_stride;
@@ -327,9 +380,35 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
     hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], s));
-    aln_launch_fill(&fa, b->is_int ? 1 : 0, b->fast ? 1 : 0, b->grid, b->lds_bytes, s);
-    HIPCHK(hipGetLastError());
-    b->fill_launches = 1;
+    b->fill_launches = 0;
+    if (b->n_small) {
+        aln_launch_fill(&fa, b->is_int ? 1 : 0, b->fast ? 1 : 0, b->grid, b->lds_bytes, s);
+        HIPCHK(hipGetLastError());
+        b->fill_launches = 1;
+    }
+    for (size_t j = 0; j < b->single_pairs.size(); ++j) {
+        const PairDesc &d = b->descs[b->single_pairs[j]];
+        SingleArgs sa{};
+        sa.seqs = b->d_seqs; sa.descs = b->d_descs; sa.pair = b->single_pairs[j]; sa.dirs = b->d_dirs;
+        sa.results = b->d_results; sa.granules = b->d_granules;
+        sa.gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
+        sa.advice = b->d_advice1; sa.zrow = b->d_advice1 + (b->single_max_n + 128);
+        sa.cand = b->d_cand; sa.ctrl = b->d_ctrl; sa.matrix = b->d_matrix;
+        sa.rows = b->params.rows; sa.cols = b->params.cols; sa.del = b->params.del; sa.ext = b->params.ext;
+        sa.semantics = b->params.semantics; sa.R = b->single_r[j];
+        sa.ns = (d.M + 64 * sa.R - 1) / (64 * sa.R);
+        sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
+        sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
+        const uint32_t lds = (uint32_t)(((uint64_t)sa.rows * sa.cols * 4 + 15) & ~15ull) + sa.cols * 64u * sa.R;
+        aln_launch_single_init(&sa, d.N + 66, s);
+        for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
+            sa.pass = pass;
+            HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 8, s));
+            aln_launch_single(&sa, lds, pass + 1 == sa.max_passes ? 1 : 0, s);
+            b->fill_launches++;
+        }
+        HIPCHK(hipGetLastError());
+    }
     if (ev) HIPCHK(hipEventRecord(ev[1], s));
     const uint32_t outs = b->params.outputs ? b->params.outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
     if (outs & ALN_OUT_TRACEBACK) {

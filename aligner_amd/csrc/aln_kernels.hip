@@ -115,6 +115,11 @@ struct Wave {
     // fast integer path only
     uint8_t *prof;            // LDS: this wave's query profile, cols x 512 bytes
     int nd4, ne4;             // -4*del, -4*ext
+    // single-pair kernel only: granule rows in / out, abort word
+    const uint64_t *gin;
+    uint64_t *gout;
+    uint32_t *abort_flag;
+    bool aborted;
 };
 
 // a better-than-b for the local end cell
@@ -250,7 +255,7 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
 // Exact for every input (it IS the reference's loop nest); used when the speculative fills do not converge
 // and on request (aln_params.force_serial).  Directions go to the row-major layout.
 template <typename SC, int SEM>
-__device__ __noinline__ void serial_fill(Wave<SC> &w)
+__device__ __noinline__ void serial_fill_impl(Wave<SC> &w)
 {
     const uint32_t N = w.N, M = w.M;
     const SC del = w.del, ext = w.ext;
@@ -313,44 +318,83 @@ __device__ __forceinline__ int prof_byte(const typename ProfWord<R>::T &pw, int 
 
 __device__ __forceinline__ int shr1_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
 
-template <int SEM, int R>
+// Inter-strip hand-off of the single-pair kernel: every boundary cell travels as one naturally aligned 8-byte granule
+// {tag = 1, value = L} written by ONE write-through (sc1) store and polled with sc1 loads -- the data is the flag, no
+// fence (cdna_hip_programming.md G16 "R2"); the buffer is zeroed before every launch so tag 0 = not yet produced.
+__device__ __forceinline__ void granule_store(uint64_t *p, int v)
+{
+    __hip_atomic_store(p, (1ull << 32) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int SEM, int R, bool SINGLE, bool FIRST>
 struct FastStrip {
     static constexpr int SPB = 16 / R;
+    static constexpr uint32_t STRIP_ROWS = SINGLE ? 64u * R : (uint32_t)ALN_STRIP_ROWS;
     using PW = typename ProfWord<R>::T;
     Wave<int> &w;
     const uint32_t strip;
-    const bool last, first;
+    const bool last;
     const int lane;
     const uint32_t N;
     uint32_t lb, rb;
+    bool zsel_on;
     int Ll[R], rbv[R];
     uint32_t rbx[R];
-    int hdiag, bottom, qoff, inchunk, qchunk;
+    int hdiag, bottom, qoff, inchunk, qchunk, outq;
     uint32_t advchunk, dw;
     PW pw;
     const uint8_t *prow;       // this lane's column of the profile: prof + lane*R
     int nd4, ne4;
 
     __device__ __forceinline__ FastStrip(Wave<int> &w_, uint32_t s, bool l)
-        : w(w_), strip(s), last(l), first(s == 0), lane(w_.lane), N(w_.N) {}
+        : w(w_), strip(s), last(l), lane(w_.lane), N(w_.N) {}
+
+    // next 64 columns of the row above this strip (L form), one per lane
+    __device__ __forceinline__ int load_boundary(uint32_t xi)
+    {
+        if constexpr (!SINGLE) {
+            return (xi < N) ? w.brow[xi + 1] : 1;
+        } else {
+            const uint64_t *src = w.gin + xi;
+            uint64_t g = 0;
+            uint32_t spins = 0;
+            for (;;) {
+                const bool need = xi < N;
+                if (need) g = granule_load(src);
+                if (__all(!need || (g >> 32) != 0)) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22) || (spins & 1023u) == 0 && __hip_atomic_load(w.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    // producer never arrived: poison the run instead of hanging the GPU
+                    if (lane == 0) __hip_atomic_store(w.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w.aborted = true;
+                    break;
+                }
+            }
+            return (xi < N) ? (int)(uint32_t)g : 1;
+        }
+    }
 
     template <bool MASKED>
     __device__ __forceinline__ void step(const uint32_t k)
     {
         if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
-            if (!first) inchunk = (xi < N) ? w.brow[xi + 1] : 1;
-            if (SEM == ALN_CORE_LOCAL && first && w.hazard) advchunk = (xi < N) ? w.advice[xi + 1] : 0u;
+            if (!FIRST) inchunk = load_boundary(xi);
+            if (SEM == ALN_CORE_LOCAL && FIRST && w.hazard) advchunk = (xi < N) ? w.advice[xi + 1] : 0u;
             qchunk = (xi + 1 < N) ? (int)w.q[xi + 1] * (64 * R) : 0;
         }
         const int sel = (int)(k & 63u);
         int top0;
-        if (first) top0 = is_local<SEM>() ? 1 : ((k + 1 == N) ? 1 + (int)(N + 1) * nd4 : 1 + (int)(k + 1) * nd4);
+        if (FIRST) top0 = is_local<SEM>() ? 1 : ((k + 1 == N) ? 1 + (int)(N + 1) * nd4 : 1 + (int)(k + 1) * nd4);
         else top0 = __builtin_amdgcn_readlane(inchunk, sel);
         const int topIn = shr1_i(top0, bottom);                 // lane 0 <- row above the strip, lane l <- lane l-1
         // cross-lane reads stay in wave-uniform control flow: inside a divergent branch the compiler may compute
         // their operand for the active lanes only
-        const uint32_t adv = (SEM == ALN_CORE_LOCAL && first) ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, sel) : 0u;
+        const uint32_t adv = (SEM == ALN_CORE_LOCAL && FIRST) ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, sel) : 0u;
         const PW pwc = pw;                                      // profile bytes of THIS step (loaded one step ago)
         qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);   // next step's query code reaches every lane
         pw = *reinterpret_cast<const PW *>(prow + qoff);
@@ -359,7 +403,7 @@ struct FastStrip {
             const uint32_t x = xm1 + 1;
             int top = topIn, diag = hdiag;
             bool zr = (topIn == 1);                             // "cell above is Beginning" -> penalty del
-            if (SEM == ALN_CORE_LOCAL && first && lane == 0) {
+            if (SEM == ALN_CORE_LOCAL && FIRST && lane == 0) {
                 // row 1: the carried penalty comes from the bottom cell of the previous column (advice)
                 zr = (k == 0) || (adv != 0);
             }
@@ -367,7 +411,7 @@ struct FastStrip {
             for (int r = 0; r < R; ++r) {
                 int negp;
                 if (SEM == ALN_CORE_LOCAL) negp = zr ? nd4 : ne4;
-                else if (SEM == ALN_CORE_GLOBAL) negp = (r == 0 && first && lane == 0 && k == 0) ? nd4 : ne4;
+                else if (SEM == ALN_CORE_GLOBAL) negp = (r == 0 && FIRST && lane == 0 && k == 0) ? nd4 : ne4;
                 else negp = nd4;
                 const int a = top + 1 + negp;
                 const int b = Ll[r] + negp;
@@ -388,12 +432,23 @@ struct FastStrip {
             }
             hdiag = topIn;
             bottom = Ll[R - 1];
-            if (!last && lane == 63) w.brow[x] = bottom;
-            if (SEM == ALN_CORE_LOCAL && last && w.hazard && (uint32_t)lane == lb) {
+            if (!SINGLE && !last && lane == 63) w.brow[x] = bottom;
+            if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) {
                 int hb = Ll[0];
 #pragma unroll
                 for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Ll[r];
                 w.zrow[x] = (hb == 1) ? 1 : 0;
+            }
+        }
+        if (SINGLE && !last) {
+            // bottom row to the strip below: lane 63's cell of column c = k - 63 enters a 64-deep lane shift register
+            // (DPP wave_shl:1); every 16 columns the newest 16 lanes publish their granules (one 128-B sc1 store)
+            outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);   // lane i <- lane i+1, lane 63 <- bottom
+            const uint32_t c = k - 63u;
+            if (k >= 63u && c < N && ((c & 15u) == 15u || c + 1 == N)) {
+                const uint32_t col = c - 63u + (uint32_t)lane;            // column held by this lane (wraps if < 0)
+                const uint32_t first_new = c & ~15u;
+                if (col >= first_new && col <= c) granule_store(w.gout + col, outq);
             }
         }
     }
@@ -401,12 +456,13 @@ struct FastStrip {
     __device__ __forceinline__ void run()
     {
         const uint32_t M = w.M;
-        const uint32_t y0 = strip * ALN_STRIP_ROWS;
+        const uint32_t y0 = strip * STRIP_ROWS;
         const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
         const uint32_t L = (rows + R - 1) / R;
-        const uint32_t nsteps = N + L - 1;
+        const uint32_t nsteps = (SINGLE && !last) ? N + 63 : N + L - 1;
         const uint32_t yb = y0 + (uint32_t)lane * R;
         lb = (rows - 1) / R; rb = (rows - 1) % R;
+        zsel_on = (SEM == ALN_CORE_LOCAL) && last && w.hazard;
         nd4 = w.nd4; ne4 = w.ne4;
         prow = w.prof + lane * R;
 
@@ -436,11 +492,11 @@ struct FastStrip {
         }
         hdiag = is_local<SEM>() || yb == 0 ? 1 : 1 + (int)yb * nd4;     // H[yb][0]; yb < M always for valid lanes
         bottom = Ll[R - 1];
-        inchunk = 1; qchunk = 0; advchunk = 0; dw = 0;
+        inchunk = 1; qchunk = 0; advchunk = 0; dw = 0; outq = 0;
         qoff = (lane == 0) ? (int)w.q[0] * (64 * R) : 0;
         pw = *reinterpret_cast<const PW *>(prow + qoff);
 
-        uint32_t *dirw = w.dirw + (strip * aln_strip_bytes(N)) / 4;
+        uint32_t *dirw = w.dirw + (size_t)strip * (SINGLE ? (size_t)((N + 63 + SPB - 1) / SPB) * 64u : (size_t)(aln_strip_bytes(N) / 4));
         const uint32_t nkb = (nsteps + SPB - 1) / SPB;
         // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
         const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
@@ -480,15 +536,28 @@ struct FastStrip {
     }
 };
 
+// The per-wave state must stay in registers on the hot path: the out-of-line serial routine gets its own copy so the
+// caller's Wave object never has its address taken.
+template <typename SC, int SEM>
+__device__ __forceinline__ void serial_fill(Wave<SC> &w)
+{
+    Wave<SC> c = w;
+    serial_fill_impl<SC, SEM>(c);
+    w.bv = c.bv; w.by = c.by; w.bx = c.bx; w.corner = c.corner;
+}
+
 template <typename SC, int SEM, int R, bool FAST>
 __device__ __forceinline__ void strip_call(Wave<SC> &w, uint32_t s, bool last)
 {
-    if constexpr (FAST) { FastStrip<SEM, R> fs(w, s, last); fs.run(); }
+    if constexpr (FAST) {
+        if (s == 0) { FastStrip<SEM, R, false, true> fs(w, s, last); fs.run(); }
+        else { FastStrip<SEM, R, false, false> fs(w, s, last); fs.run(); }
+    }
     else run_strip<SC, SEM, R>(w, s, last);
 }
 
 template <typename SC, int SEM, bool FAST>
-__device__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair_result &res)
+__device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair_result &res)
 {
     using O = ScOps<SC>;
     const int lane = w.lane;
@@ -631,6 +700,150 @@ __global__ __launch_bounds__(256) void aln_fill_kernel(FillArgs a)
 }
 
 
+// ---------------------------------------------------------------- single-pair kernel: one wave per strip
+// Grid = number of strips; strip s consumes the granule row strip s-1 publishes 16 columns at a time, so the strips
+// form a software pipeline across CUs (lag per strip ~ 64 + 63 steps + one L2 round trip).  Every wave that waits
+// polls a bounded number of times and then poisons the run (ctrl[0]) instead of hanging.
+template <int SEM, int R>
+__global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
+{
+    if (__hip_atomic_load(a.ctrl + 1 + a.pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *S = reinterpret_cast<int *>(smem);
+    const int *gm = reinterpret_cast<const int *>(a.matrix);
+    for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
+    __syncthreads();
+    const PairDesc &desc = a.descs[a.pair];
+    Wave<int> w;
+    w.lane = threadIdx.x & 63;
+    w.N = desc.N; w.M = desc.M;
+    w.q = a.seqs + desc.q_off;
+    w.t = a.seqs + desc.t_off;
+    w.S = S; w.cols = a.cols;
+    w.del = (int)a.del; w.ext = (int)a.ext;
+    w.nd4 = -4 * (int)a.del; w.ne4 = -4 * (int)a.ext;
+    w.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u);
+    w.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
+    w.brow = nullptr; w.hmat = nullptr;
+    w.advice = a.advice; w.zrow = a.zrow;
+    w.hazard = a.hazard != 0;
+    w.bv = (SEM == ALN_LEGACY_LOCAL) ? -3 : INT_MIN; w.by = 0; w.bx = 0; w.corner = 0;
+    const uint32_t strip = blockIdx.x;
+    const bool last = strip + 1 == a.ns;
+    w.gin = a.granules + (uint64_t)(strip ? strip - 1 : 0) * a.gstride;
+    w.gout = a.granules + (uint64_t)strip * a.gstride;
+    w.abort_flag = a.ctrl;
+    w.aborted = false;
+    if (strip == 0) { FastStrip<SEM, R, true, true> fs(w, strip, last); fs.run(); }
+    else { FastStrip<SEM, R, true, false> fs(w, strip, last); fs.run(); }
+    if (is_local<SEM>()) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int ov = __shfl_xor(w.bv, m);
+            const uint32_t oy = (uint32_t)__shfl_xor((int)w.by, m), ox = (uint32_t)__shfl_xor((int)w.bx, m);
+            if (ox != 0 && (w.bx == 0 || better<int, SEM>(ov, oy, ox, w.bv, w.by, w.bx))) { w.bv = ov; w.by = oy; w.bx = ox; }
+        }
+    }
+    if (w.lane == 0) {
+        int32_t *c = a.cand + 4 * strip;
+        c[0] = w.bv; c[1] = (int32_t)w.by; c[2] = (int32_t)w.bx; c[3] = w.corner;
+    }
+}
+
+// One wave: folds the per-strip candidates, checks the row-1 advice against the bottom row this pass produced and
+// either publishes the result or arms the next pass (ctrl[1 + pass + 1]) / the serial fallback (ctrl[15]).
+template <int SEM>
+__global__ __launch_bounds__(64) void aln_single_finalize_kernel(SingleArgs a)
+{
+    if (__hip_atomic_load(a.ctrl + 1 + a.pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const int lane = threadIdx.x;
+    PairDesc &desc = a.descs[a.pair];
+    aln_pair_result &res = a.results[a.pair];
+    const uint32_t N = desc.N, M = desc.M;
+    int bv = (SEM == ALN_LEGACY_LOCAL) ? -3 : INT_MIN;
+    uint32_t by = 0, bx = 0;
+    for (uint32_t s = lane; s < a.ns; s += 64) {
+        const int32_t *c = a.cand + 4 * s;
+        if (c[2] != 0 && (bx == 0 || better<int, SEM>(c[0], (uint32_t)c[1], (uint32_t)c[2], bv, by, bx))) { bv = c[0]; by = c[1]; bx = c[2]; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int ov = __shfl_xor(bv, m);
+        const uint32_t oy = (uint32_t)__shfl_xor((int)by, m), ox = (uint32_t)__shfl_xor((int)bx, m);
+        if (ox != 0 && (bx == 0 || better<int, SEM>(ov, oy, ox, bv, by, bx))) { bv = ov; by = oy; bx = ox; }
+    }
+    int mismatch = 0;
+    if (a.hazard) for (uint32_t x = 2 + lane; x <= N; x += 64) mismatch |= (a.advice[x] != a.zrow[x - 1]);
+    const bool again = __any(mismatch);
+    const bool aborted = a.ctrl[0] != 0;
+    if (again && !aborted) {
+        for (uint32_t x = 2 + lane; x <= N; x += 64) a.advice[x] = a.zrow[x - 1];
+        if (lane == 0) {
+            if (a.pass + 1 < a.max_passes) a.ctrl[1 + a.pass + 1] = 1;
+            else a.ctrl[15] = a.pass + 1;               // not self-consistent within the cap: strict-order kernel
+        }
+        return;
+    }
+    if (lane == 0) {
+        const int corner = a.cand[4 * (a.ns - 1) + 3] >> 2;
+        desc.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
+        res.passes = a.pass + 1; res.flags = 1u;
+        res.start_y = res.start_x = 0; res.aln_len = 0;
+        res.status = aborted ? ALN_ERR_DEVICE : ALN_OK;
+        if (is_local<SEM>()) {
+            const int v = bv >> 2;
+            res.score = res.f = (double)v;
+            res.end_y = by; res.end_x = bx;
+            if (SEM == ALN_CORE_LOCAL && !(v > 0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
+        } else {
+            res.score = (double)corner;
+            res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : (double)corner;
+            res.end_y = M; res.end_x = N;
+        }
+    }
+}
+
+// Strict reference order for one (large) pair; runs only when ctrl[15] is armed.  scratch holds M + 1 ints.
+template <int SEM>
+__global__ __launch_bounds__(64) void aln_single_serial_kernel(SingleArgs a)
+{
+    if (a.ctrl[15] == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *S = reinterpret_cast<int *>(smem);
+    const int *gm = reinterpret_cast<const int *>(a.matrix);
+    for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    PairDesc &desc = a.descs[a.pair];
+    aln_pair_result &res = a.results[a.pair];
+    Wave<int> w;
+    w.lane = 0; w.N = desc.N; w.M = desc.M;
+    w.q = a.seqs + desc.q_off; w.t = a.seqs + desc.t_off;
+    w.S = S; w.cols = a.cols; w.del = (int)a.del; w.ext = (int)a.ext;
+    w.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
+    w.brow = reinterpret_cast<int *>(a.granules);
+    w.hmat = nullptr;
+    serial_fill_impl<int, SEM>(w);
+    desc.layout = ALN_LAYOUT_ROWMAJOR;
+    res.passes = a.ctrl[15] | 0x80u; res.flags = 1u;
+    res.start_y = res.start_x = 0; res.aln_len = 0; res.status = ALN_OK;
+    if (is_local<SEM>()) {
+        res.score = res.f = (double)w.bv; res.end_y = w.by; res.end_x = w.bx;
+        if (SEM == ALN_CORE_LOCAL && !(w.bv > 0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
+    } else {
+        res.score = (double)w.corner; res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : (double)w.corner;
+        res.end_y = desc.M; res.end_x = desc.N;
+    }
+}
+
+// arms pass 0 and clears the advice / bottom-row bytes
+extern "C" __global__ void aln_single_init_kernel(SingleArgs a, uint32_t n_bytes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_bytes) { a.advice[i] = 0; a.zrow[i] = 0; }
+    if (i < 16) a.ctrl[i] = (i == 1) ? 1u : 0u;
+}
+
 // ---------------------------------------------------------------- traceback
 // Direction of cell (y, x) from the packed store (borders are implicit: simple/mod.rs:55-67).
 __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bool global, uint32_t y, uint32_t x)
@@ -644,14 +857,25 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
         const uint32_t rowbytes = (d.N + 4) / 4;
         return (base[(size_t)y * rowbytes + (x >> 2)] >> (2 * (x & 3u))) & 3;
     }
-    const uint32_t strip = (y - 1) / ALN_STRIP_ROWS;
-    const uint32_t ns = aln_num_strips(d.M);
-    const int R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8;
-    const uint32_t i = (y - 1) - strip * ALN_STRIP_ROWS;
+    uint32_t strip, i;
+    int R;
+    uint64_t strip_bytes;
+    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) {
+        R = (int)((d.layout >> 8) & 0xffu);
+        strip = (y - 1) / (64u * R);
+        i = (y - 1) - strip * 64u * R;
+        strip_bytes = (uint64_t)((d.N + 63 + 16 / R - 1) / (16 / R)) * 256u;
+    } else {
+        strip = (y - 1) / ALN_STRIP_ROWS;
+        const uint32_t ns = aln_num_strips(d.M);
+        R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8;
+        i = (y - 1) - strip * ALN_STRIP_ROWS;
+        strip_bytes = aln_strip_bytes(d.N);
+    }
     const uint32_t lane = i / R, r = i % R;
     const uint32_t k = (x - 1) + lane;
     const uint32_t spb = 16 / R;
-    const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_strip_bytes(d.N));
+    const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * strip_bytes);
     const uint32_t word = wbase[(k / spb) * 64 + lane];
     return aln_tag_to_dir((int)((word >> aln_dir_bitpos(k, r, lane, d.N, R)) & 3u));
 }
@@ -727,6 +951,30 @@ extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_
         else ALN_LAUNCH(double, ALN_CORE_LOCAL, false);
     }
 #undef ALN_LAUNCH
+}
+extern "C" void aln_launch_single(const SingleArgs *a, uint32_t lds_bytes, int with_serial, hipStream_t s)
+{
+    const dim3 g(a->ns), b(64);
+#define ALN_SINGLE(SEM)                                                                                        \
+    do {                                                                                                       \
+        if (a->R == 1) hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 1>), g, b, lds_bytes, s, *a);          \
+        else if (a->R == 2) hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 2>), g, b, lds_bytes, s, *a);     \
+        else if (a->R == 4) hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 4>), g, b, lds_bytes, s, *a);     \
+        else hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 8>), g, b, lds_bytes, s, *a);                     \
+        hipLaunchKernelGGL((aln_single_finalize_kernel<SEM>), dim3(1), b, 0, s, *a);                           \
+        if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<SEM>), dim3(1), b, lds_bytes, s, *a);    \
+    } while (0)
+    switch (a->semantics) {
+    case ALN_CORE_GLOBAL: ALN_SINGLE(ALN_CORE_GLOBAL); break;
+    case ALN_CORE_LOCAL: ALN_SINGLE(ALN_CORE_LOCAL); break;
+    case ALN_LEGACY_GLOBAL: ALN_SINGLE(ALN_LEGACY_GLOBAL); break;
+    default: ALN_SINGLE(ALN_LEGACY_LOCAL); break;
+    }
+#undef ALN_SINGLE
+}
+extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(aln_single_init_kernel, dim3((n_bytes + 255) / 256), dim3(256), 0, s, *a, n_bytes);
 }
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
 {
