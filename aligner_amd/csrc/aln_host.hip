@@ -293,7 +293,9 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     const uint64_t sc_size = b->is_int ? 4 : 8;
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
-    b->scratch_stride = brow_bytes + 2 * adv_bytes;
+    // + 4 checkpoints of strip 0's lane state (26 ints x 64 lanes) and a copy of strip 0's bottom row (fast path)
+    const uint64_t ck_bytes = b->fast ? (4ull * 26 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
+    b->scratch_stride = brow_bytes + 2 * adv_bytes + ck_bytes;
     b->lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
     if (b->fast) { b->prof_stride = cols * 512u; b->lds_bytes += 4u * b->prof_stride; }
 
@@ -377,6 +379,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     fa.matrix = b->d_matrix; fa.rows = b->params.rows; fa.cols = b->params.cols; fa.prof_stride = b->prof_stride;
     fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
     fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
+    fa.no_repair = getenv("ALN_NO_REPAIR") ? 1u : 0u;
     fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
     hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], s));

@@ -115,6 +115,13 @@ struct Wave {
     // fast integer path only
     uint8_t *prof;            // LDS: this wave's query profile, cols x 512 bytes
     int nd4, ne4;             // -4*del, -4*ext
+    // localized repair of the row-1 hazard (batch fast path): checkpoints of strip 0's lane state, a copy of strip 0's
+    // bottom row, the mode of the current strip-0 run and its outcome
+    int *ckpt;                // 4 checkpoints x 26 fields x 64 lanes
+    int *brow0;               // strip 0's bottom row as produced by the checkpointed pass (multi-strip pairs)
+    int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair (compare, stop at the first matching checkpoint)
+    uint32_t last_flip;       // largest column whose advice differs from the checkpointed pass
+    bool repaired, brow_bad;
     // single-pair kernel only: granule rows in / out, abort word
     const uint64_t *gin;
     uint64_t *gout;
@@ -432,7 +439,13 @@ struct FastStrip {
             }
             hdiag = topIn;
             bottom = Ll[R - 1];
-            if (!SINGLE && !last && lane == 63) w.brow[x] = bottom;
+            if (!SINGLE && !last && lane == 63) {
+                if (FIRST && SEM == ALN_CORE_LOCAL && w.ck_mode == 2) { if (w.brow0[x] != bottom) w.brow_bad = true; }
+                else {
+                    w.brow[x] = bottom;
+                    if (FIRST && SEM == ALN_CORE_LOCAL && w.ck_mode == 1) w.brow0[x] = bottom;
+                }
+            }
             if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) {
                 int hb = Ll[0];
 #pragma unroll
@@ -451,6 +464,24 @@ struct FastStrip {
                 if (col >= first_new && col <= c) granule_store(w.gout + col, outq);
             }
         }
+    }
+
+    // Lane state at a block boundary (direction word flushed, input chunks about to be reloaded): everything the
+    // rest of the strip depends on besides the inputs.  save = store it, !save = "is it identical to the stored one".
+    __device__ __forceinline__ bool checkpoint(uint32_t slot, bool save)
+    {
+        int *base = w.ckpt + slot * (26 * 64) + lane;
+        bool same = true;
+        int f = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (save) { base[(f) * 64] = Ll[r]; base[(f + 1) * 64] = rbv[r]; base[(f + 2) * 64] = (int)rbx[r]; }
+            else same = same && base[f * 64] == Ll[r] && base[(f + 1) * 64] == rbv[r] && base[(f + 2) * 64] == (int)rbx[r];
+            f += 3;
+        }
+        if (save) { base[24 * 64] = hdiag; base[25 * 64] = bottom; }
+        else same = same && base[24 * 64] == hdiag && base[25 * 64] == bottom;
+        return same;
     }
 
     __device__ __forceinline__ void run()
@@ -501,22 +532,41 @@ struct FastStrip {
         // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
         const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
         const uint32_t kb_steady1 = max(kb_steady0, min(nkb, N / SPB));
+        // Strip 0 of a hazard pair runs in segments that end at the checkpoint steps 64, 128, 256, 512.
+        const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && w.ck_mode != 0;
+        uint32_t next_ck = ckmode ? 64u : 0xffffffffu, slot = 0;
         uint32_t kb = 0;
-        for (; kb < kb_steady0; ++kb) {
+        while (kb < nkb) {
+            const uint32_t seg_end = (next_ck == 0xffffffffu) ? nkb : min(nkb, next_ck / SPB);
+            const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
+            for (; kb < e0; ++kb) {
 #pragma unroll
-            for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
-            dirw[kb * 64 + lane] = dw;
-        }
-        for (; kb < kb_steady1; ++kb) {
+                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
+                dirw[kb * 64 + lane] = dw;
+            }
+            for (; kb < e1; ++kb) {
 #pragma unroll
-            for (int kk = 0; kk < SPB; ++kk) step<false>(kb * SPB + kk);
-            dirw[kb * 64 + lane] = dw;
-        }
-        for (; kb < nkb; ++kb) {
+                for (int kk = 0; kk < SPB; ++kk) step<false>(kb * SPB + kk);
+                dirw[kb * 64 + lane] = dw;
+            }
+            for (; kb < seg_end; ++kb) {
 #pragma unroll
-            for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
-            dirw[kb * 64 + lane] = dw;
+                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
+                dirw[kb * 64 + lane] = dw;
+            }
+            if (ckmode && kb < nkb && kb * SPB == next_ck) {
+                if (w.ck_mode == 1) checkpoint(slot, true);
+                else if (__all(checkpoint(slot, false)) && w.last_flip <= next_ck) {
+                    // every lane is in exactly the state the checkpointed pass had here and no advice differs from
+                    // here on: the rest of this strip -- and so of the whole fill -- is unchanged
+                    w.repaired = true;
+                    return;
+                }
+                ++slot;
+                next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
+            }
         }
+        if (ckmode && w.ck_mode == 2) return;          // ran out of checkpoints: the caller escalates to a full pass
 
         if (is_local<SEM>()) {
 #pragma unroll
@@ -581,30 +631,75 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
     uint32_t passes = 0;
     bool converged = false;
     const uint32_t max_passes = a.max_passes ? a.max_passes : 4u;
+    const uint32_t ns = aln_num_strips(M);
+    // one full fill of every strip with the current advice
+    auto full_pass = [&](int ck_mode) {
+        w.ck_mode = ck_mode;
+        w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)(FAST ? -3 : -1) : O::lowest();
+        w.by = 0; w.bx = 0;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const bool last = (s + 1 == ns);
+            if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
+            const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8;
+            if (R == 8) strip_call<SC, SEM, 8, FAST>(w, s, last);
+            else if (R == 4) strip_call<SC, SEM, 4, FAST>(w, s, last);
+            else if (R == 2) strip_call<SC, SEM, 2, FAST>(w, s, last);
+            else strip_call<SC, SEM, 1, FAST>(w, s, last);
+        }
+        ++passes;
+        __threadfence_block();
+    };
+    // self-consistency: the advice used for row 1 must equal the bottom row the fill produced.  Returns true when it
+    // does; otherwise adopts the observed bottom row as the new advice and reports the largest changed column.
+    auto adopt_advice = [&](uint32_t &last_flip) -> bool {
+        int mismatch = 0;
+        uint32_t lf = 0;
+        for (uint32_t x = 2 + lane; x <= N; x += 64) {
+            const uint8_t z = w.zrow[x - 1];
+            if (w.advice[x] != z) { mismatch = 1; w.advice[x] = z; }
+            if (z != 0) lf = x;                      // advice differs from the all-"ext" first pass here
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) lf = max(lf, (uint32_t)__shfl_xor((int)lf, m));
+        last_flip = lf;
+        __threadfence_block();
+        return !__any(mismatch);
+    };
     if (!a.force_serial) {
-        const uint32_t ns = aln_num_strips(M);
-        do {
-            w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)(FAST ? -3 : -1) : O::lowest();
-            w.by = 0; w.bx = 0;
-            for (uint32_t s = 0; s < ns; ++s) {
-                const bool last = (s + 1 == ns);
-                if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
-                const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8;
-                if (R == 8) strip_call<SC, SEM, 8, FAST>(w, s, last);
-                else if (R == 4) strip_call<SC, SEM, 4, FAST>(w, s, last);
-                else if (R == 2) strip_call<SC, SEM, 2, FAST>(w, s, last);
-                else strip_call<SC, SEM, 1, FAST>(w, s, last);
+        w.ck_mode = 0; w.repaired = false; w.brow_bad = false; w.last_flip = 0;
+        const bool can_repair = FAST && w.hazard && !a.no_repair;
+        full_pass(can_repair ? 1 : 0);
+        if (!w.hazard) converged = true;
+        else {
+            uint32_t last_flip = 0, repairs = 0;
+            converged = adopt_advice(last_flip);
+            // Localized repair: bottom-row zeros sit next to the left border, so only the first columns of strip 0 see
+            // a different penalty.  Re-run strip 0 with the new advice until its lane state rejoins the checkpointed
+            // first pass; if it never does (or strip 0's bottom row changed) fall back to full passes.
+            if constexpr (FAST && SEM == ALN_CORE_LOCAL) {
+                while (!converged && can_repair && repairs < 8 && last_flip <= 512) {
+                    ++repairs;
+                    w.ck_mode = 2; w.repaired = false; w.brow_bad = false; w.last_flip = last_flip;
+                    const bool last0 = (ns == 1);
+                    const int R0 = last0 ? aln_pick_r(M) : 8;
+                    if (R0 == 8) { FastStrip<SEM, 8, false, true> fs(w, 0, last0); fs.run(); }
+                    else if (R0 == 4) { FastStrip<SEM, 4, false, true> fs(w, 0, last0); fs.run(); }
+                    else if (R0 == 2) { FastStrip<SEM, 2, false, true> fs(w, 0, last0); fs.run(); }
+                    else { FastStrip<SEM, 1, false, true> fs(w, 0, last0); fs.run(); }
+                    __threadfence_block();
+                    passes += 0x100u;                                   // repairs are counted in bits 8..15
+                    if (!__any(w.repaired) || __any(w.brow_bad)) break;  // escalate
+                    if (ns > 1) { converged = true; break; }            // the bottom strip, hence z, is untouched
+                    converged = adopt_advice(last_flip);                // single strip: z may have moved, iterate
+                }
             }
-            ++passes;
-            if (!w.hazard) { converged = true; break; }
-            // self-consistency: the advice used for row 1 must equal the bottom row this fill produced
-            __threadfence_block();
-            int mismatch = 0;
-            for (uint32_t x = 2 + lane; x <= N; x += 64) mismatch |= (w.advice[x] != w.zrow[x - 1]);
-            if (!__any(mismatch)) { converged = true; break; }
-            for (uint32_t x = 2 + lane; x <= N; x += 64) w.advice[x] = w.zrow[x - 1];
-            __threadfence_block();
-        } while (passes < max_passes);
+            w.ck_mode = 0;
+            while (!converged && (passes & 0xffu) < max_passes) {
+                full_pass(0);
+                uint32_t lf;
+                converged = adopt_advice(lf);
+            }
+        }
     }
     uint32_t layout = ALN_LAYOUT_SKEW;
     if (!converged) {
@@ -671,6 +766,9 @@ __global__ __launch_bounds__(256) void aln_fill_kernel(FillArgs a)
     w.brow = reinterpret_cast<SC *>(sc);
     w.advice = sc + brow_bytes;
     w.zrow = sc + brow_bytes + adv_bytes;
+    w.ckpt = reinterpret_cast<int *>(sc + brow_bytes + 2 * adv_bytes);
+    w.brow0 = w.ckpt + 4 * 26 * 64;
+    w.ck_mode = 0; w.last_flip = 0; w.repaired = false; w.brow_bad = false;
     w.S = S;
     w.cols = a.cols;
     w.del = ScOps<SC>::from_double(a.del);
@@ -734,6 +832,7 @@ __global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
     w.gout = a.granules + (uint64_t)strip * a.gstride;
     w.abort_flag = a.ctrl;
     w.aborted = false;
+    w.ckpt = nullptr; w.brow0 = nullptr; w.ck_mode = 0; w.last_flip = 0; w.repaired = false; w.brow_bad = false;
     if (strip == 0) { FastStrip<SEM, R, true, true> fs(w, strip, last); fs.run(); }
     else { FastStrip<SEM, R, true, false> fs(w, strip, last); fs.run(); }
     if (is_local<SEM>()) {
