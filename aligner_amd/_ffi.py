@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaligner_hip.so")
+LIB_PATH = os.environ.get("ALN_LIB") or os.path.join(_HERE, "lib", "libaligner_hip.so")
 
 # enum aln_semantics
 CORE_GLOBAL, CORE_LOCAL, LEGACY_GLOBAL, LEGACY_LOCAL = 0, 1, 2, 3

@@ -356,17 +356,28 @@ struct FastStrip {
     PW pw;
     const uint8_t *prow;       // this lane's column of the profile: prof + lane*R
     int nd4, ne4;
+    // copies of the per-pair fields the inner loop touches (kept out of the Wave object so they stay in registers)
+    const uint8_t *q_;
+    int *brow_, *brow0_;
+    uint8_t *advice_, *zrow_;
+    const uint64_t *gin_;
+    uint64_t *gout_;
+    uint32_t *abort_;
+    bool hazard_, brow_bad_, aborted_;
+    int ck_mode_;
 
     __device__ __forceinline__ FastStrip(Wave<int> &w_, uint32_t s, bool l)
-        : w(w_), strip(s), last(l), lane(w_.lane), N(w_.N) {}
+        : w(w_), strip(s), last(l), lane(w_.lane), N(w_.N), q_(w_.q), brow_(w_.brow), brow0_(w_.brow0),
+          advice_(w_.advice), zrow_(w_.zrow), gin_(w_.gin), gout_(w_.gout), abort_(w_.abort_flag), hazard_(w_.hazard),
+          brow_bad_(false), aborted_(false), ck_mode_(w_.ck_mode) {}
 
     // next 64 columns of the row above this strip (L form), one per lane
     __device__ __forceinline__ int load_boundary(uint32_t xi)
     {
         if constexpr (!SINGLE) {
-            return (xi < N) ? w.brow[xi + 1] : 1;
+            return (xi < N) ? brow_[xi + 1] : 1;
         } else {
-            const uint64_t *src = w.gin + xi;
+            const uint64_t *src = gin_ + xi;
             uint64_t g = 0;
             uint32_t spins = 0;
             for (;;) {
@@ -374,10 +385,10 @@ struct FastStrip {
                 if (need) g = granule_load(src);
                 if (__all(!need || (g >> 32) != 0)) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22) || (spins & 1023u) == 0 && __hip_atomic_load(w.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (++spins > (1u << 22) || (spins & 1023u) == 0 && __hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     // producer never arrived: poison the run instead of hanging the GPU
-                    if (lane == 0) __hip_atomic_store(w.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w.aborted = true;
+                    if (lane == 0) __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    aborted_ = true;
                     break;
                 }
             }
@@ -391,8 +402,8 @@ struct FastStrip {
         if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
             if (!FIRST) inchunk = load_boundary(xi);
-            if (SEM == ALN_CORE_LOCAL && FIRST && w.hazard) advchunk = (xi < N) ? w.advice[xi + 1] : 0u;
-            qchunk = (xi + 1 < N) ? (int)w.q[xi + 1] * (64 * R) : 0;
+            if (SEM == ALN_CORE_LOCAL && FIRST && hazard_) advchunk = (xi < N) ? advice_[xi + 1] : 0u;
+            qchunk = (xi + 1 < N) ? (int)q_[xi + 1] * (64 * R) : 0;
         }
         const int sel = (int)(k & 63u);
         int top0;
@@ -440,17 +451,17 @@ struct FastStrip {
             hdiag = topIn;
             bottom = Ll[R - 1];
             if (!SINGLE && !last && lane == 63) {
-                if (FIRST && SEM == ALN_CORE_LOCAL && w.ck_mode == 2) { if (w.brow0[x] != bottom) w.brow_bad = true; }
+                if (FIRST && SEM == ALN_CORE_LOCAL && ck_mode_ == 2) { if (brow0_[x] != bottom) brow_bad_ = true; }
                 else {
-                    w.brow[x] = bottom;
-                    if (FIRST && SEM == ALN_CORE_LOCAL && w.ck_mode == 1) w.brow0[x] = bottom;
+                    brow_[x] = bottom;
+                    if (FIRST && SEM == ALN_CORE_LOCAL && ck_mode_ == 1) brow0_[x] = bottom;
                 }
             }
             if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) {
                 int hb = Ll[0];
 #pragma unroll
                 for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Ll[r];
-                w.zrow[x] = (hb == 1) ? 1 : 0;
+                zrow_[x] = (hb == 1) ? 1 : 0;
             }
         }
         if (SINGLE && !last) {
@@ -461,7 +472,7 @@ struct FastStrip {
             if (k >= 63u && c < N && ((c & 15u) == 15u || c + 1 == N)) {
                 const uint32_t col = c - 63u + (uint32_t)lane;            // column held by this lane (wraps if < 0)
                 const uint32_t first_new = c & ~15u;
-                if (col >= first_new && col <= c) granule_store(w.gout + col, outq);
+                if (col >= first_new && col <= c) granule_store(gout_ + col, outq);
             }
         }
     }
@@ -493,7 +504,7 @@ struct FastStrip {
         const uint32_t nsteps = (SINGLE && !last) ? N + 63 : N + L - 1;
         const uint32_t yb = y0 + (uint32_t)lane * R;
         lb = (rows - 1) / R; rb = (rows - 1) % R;
-        zsel_on = (SEM == ALN_CORE_LOCAL) && last && w.hazard;
+        zsel_on = (SEM == ALN_CORE_LOCAL) && last && hazard_;
         nd4 = w.nd4; ne4 = w.ne4;
         prow = w.prof + lane * R;
 
@@ -524,7 +535,7 @@ struct FastStrip {
         hdiag = is_local<SEM>() || yb == 0 ? 1 : 1 + (int)yb * nd4;     // H[yb][0]; yb < M always for valid lanes
         bottom = Ll[R - 1];
         inchunk = 1; qchunk = 0; advchunk = 0; dw = 0; outq = 0;
-        qoff = (lane == 0) ? (int)w.q[0] * (64 * R) : 0;
+        qoff = (lane == 0) ? (int)q_[0] * (64 * R) : 0;
         pw = *reinterpret_cast<const PW *>(prow + qoff);
 
         uint32_t *dirw = w.dirw + (size_t)strip * (SINGLE ? (size_t)((N + 63 + SPB - 1) / SPB) * 64u : (size_t)(aln_strip_bytes(N) / 4));
@@ -533,7 +544,7 @@ struct FastStrip {
         const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
         const uint32_t kb_steady1 = max(kb_steady0, min(nkb, N / SPB));
         // Strip 0 of a hazard pair runs in segments that end at the checkpoint steps 64, 128, 256, 512.
-        const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && w.ck_mode != 0;
+        const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && ck_mode_ != 0;
         uint32_t next_ck = ckmode ? 64u : 0xffffffffu, slot = 0;
         uint32_t kb = 0;
         while (kb < nkb) {
@@ -555,18 +566,21 @@ struct FastStrip {
                 dirw[kb * 64 + lane] = dw;
             }
             if (ckmode && kb < nkb && kb * SPB == next_ck) {
-                if (w.ck_mode == 1) checkpoint(slot, true);
+                if (ck_mode_ == 1) checkpoint(slot, true);
                 else if (__all(checkpoint(slot, false)) && w.last_flip <= next_ck) {
                     // every lane is in exactly the state the checkpointed pass had here and no advice differs from
                     // here on: the rest of this strip -- and so of the whole fill -- is unchanged
                     w.repaired = true;
+                    w.brow_bad = brow_bad_;
                     return;
                 }
                 ++slot;
                 next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
             }
         }
-        if (ckmode && w.ck_mode == 2) return;          // ran out of checkpoints: the caller escalates to a full pass
+        w.brow_bad = brow_bad_;
+        w.aborted = w.aborted || aborted_;
+        if (ckmode && ck_mode_ == 2) return;           // ran out of checkpoints: the caller escalates to a full pass
 
         if (is_local<SEM>()) {
 #pragma unroll
@@ -591,7 +605,9 @@ struct FastStrip {
 template <typename SC, int SEM>
 __device__ __forceinline__ void serial_fill(Wave<SC> &w)
 {
-    Wave<SC> c = w;
+    Wave<SC> c;
+    c.lane = 0; c.N = w.N; c.M = w.M; c.q = w.q; c.t = w.t; c.S = w.S; c.cols = w.cols; c.del = w.del; c.ext = w.ext;
+    c.dirw = w.dirw; c.brow = w.brow; c.hmat = w.hmat;
     serial_fill_impl<SC, SEM>(c);
     w.bv = c.bv; w.by = c.by; w.bx = c.bx; w.corner = c.corner;
 }
@@ -749,7 +765,7 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
 
 // ---------------------------------------------------------------- fill kernel: persistent waves over a work queue
 template <typename SC, int SEM, bool FAST>
-__global__ __launch_bounds__(256) void aln_fill_kernel(FillArgs a)
+__global__ __launch_bounds__(256, FAST ? 3 : 2) void aln_fill_kernel(FillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SC *S = reinterpret_cast<SC *>(smem);
@@ -979,6 +995,50 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
     return aln_tag_to_dir((int)((word >> aln_dir_bitpos(k, r, lane, d.N, R)) & 3u));
 }
 
+// Touches the direction words the next ~16 traceback steps will need (the path moves up/left: blocks kb, kb-1, ...
+// of the current lane and of the lanes just above it).  The walk is one dependent load per step; loads return in
+// order, so the look-ahead is issued as ONE burst of independent loads (one HBM round trip) after which the next
+// ~16 demand loads hit L1/L2.  Returns a value derived from the loaded words so that the loads stay live.
+__device__ __forceinline__ uint32_t dir_prefetch(const uint8_t *dirs, const PairDesc &d, uint32_t y, uint32_t x)
+{
+    if (y == 0 || x == 0 || d.layout == ALN_LAYOUT_ROWMAJOR) return 0;
+    const uint8_t *base = dirs + d.dir_off;
+    uint32_t strip, i;
+    int R;
+    uint64_t strip_bytes;
+    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) {
+        R = (int)((d.layout >> 8) & 0xffu);
+        strip = (y - 1) / (64u * R);
+        i = (y - 1) - strip * 64u * R;
+        strip_bytes = (uint64_t)((d.N + 63 + 16 / R - 1) / (16 / R)) * 256u;
+    } else {
+        strip = (y - 1) / ALN_STRIP_ROWS;
+        const uint32_t ns = aln_num_strips(d.M);
+        R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8;
+        i = (y - 1) - strip * ALN_STRIP_ROWS;
+        strip_bytes = aln_strip_bytes(d.N);
+    }
+    const uint32_t lane = i / R, spb = 16u / R;
+    const uint32_t kb = ((x - 1) + lane) / spb;
+    const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * strip_bytes);
+    const uint32_t J = 16u / spb + 1u;                   // blocks covered by 16 steps
+    const uint32_t drift = (spb + R - 1) / R;            // lanes the path can climb per block
+    uint32_t v[18];
+#pragma unroll
+    for (uint32_t j = 0; j < 9; ++j) {
+        const uint32_t jj = j < J ? j : J;
+        const uint32_t b = kb >= jj ? kb - jj : 0;
+        const uint32_t la = lane >= jj * drift / 2 ? lane - jj * drift / 2 : 0;
+        const uint32_t lb = la >= 12 ? la - 12 : 0;
+        v[2 * j] = wbase[b * 64 + la];
+        v[2 * j + 1] = wbase[b * 64 + lb];
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) acc |= v[j];
+    return acc;
+}
+
 // One thread per pair: the reference's pointer chase (simple/mod.rs:99-130, :213-245; legacy :146-176, :232-261),
 // including the duplicated seed pair.  Strings are written back to front, then reversed in place.
 extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs a)
@@ -996,8 +1056,9 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     qa[0] = q[cx - 1];
     ta[0] = t[cy - 1];
     if (legacy) { cy -= 1; cx -= 1; }   // legacy starts at the diagonal predecessor (aligner_core.rs:146-147, :232-233)
-    uint32_t len = 1;
+    uint32_t len = 1, keep = 0;
     for (;;) {
+        if ((len & 15u) == 1u) keep |= dir_prefetch(a.dirs, d, cy, cx);
         const int dd = dir_at(a.dirs, d, global, cy, cx);
         if (dd == D_BEG) break;
         if (dd == D_TOP) { qa[len] = a.blank; ta[len] = t[cy - 1]; cy--; }
@@ -1011,6 +1072,7 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     }
     res.start_y = cy; res.start_x = cx;
     res.aln_len = len;
+    if (keep == 0x9e3779b9u && len == 0xffffffffu) res.flags |= 0x80000000u;   // never true: keeps the look-ahead loads
 }
 
 // (M+1)x(N+1) Direction bytes for one pair = AlignmentResult.direction_matrix
