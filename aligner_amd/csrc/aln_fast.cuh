@@ -1,0 +1,398 @@
+// aln_fast.cuh -- the fast integer fill path (included by aln_kernels.hip inside its anonymous namespace).
+//
+// Same recurrence as the generic path, reformulated so that ONE v_max3_i32 yields value AND direction:
+//   carried state   T = 4*H + 2                              (H exact in the upper 30 bits)
+//   Top  key = Ttop  - 4p       (tag 2)      Left key = Tleft - 4p - 1 (tag 1)      Diag key = Tdiag + (4s - 2) (tag 0)
+//   key = max3(..)  ->  H' = key >> 2,  tag = key & 3, in the reference's tie order Top > Left > Diagonal (enums.rs:18-28)
+//   T' = (key & ~3) | 2          Beginning (H' == 0, local, enums.rs:37) is tag 3; the legacy clamp at zero
+//                                (aligner_core.rs:210) is max(key, 3).
+// Substitution scores come from a per-strip query profile in LDS, P[c][row] = 4*S[t[row]][c] - 2 as int8, row-contiguous
+// per code: one ds_read of R bytes per step feeds the lane's R cells (SDWA byte adds), conflict-free by construction.
+// The query code flows down the lanes with the same DPP wave_shr:1 that carries the boundary cell.
+// Local end cell: per row one packed register  (T' << 11) | f(step)  updated with ONE v_max per cell, folded every 2048
+// steps with the exact tie rule (first in row-major order: core; last in column-major order: legacy).
+// Per cell (core local): v_cmp, v_cndmask (penalty), v_add, v_add3, v_add_sdwa, v_max3, v_and_or, v_cndmask (tag 3),
+// v_alignbit, v_lshl_add, v_max = 11 VALU ops; core global / legacy global: 6.
+#pragma once
+
+// ---- single instructions the compiler would otherwise re-associate into longer sequences
+__device__ __forceinline__ int v_max3(int a, int b, int c)
+{
+    int d;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int v_tform(int key)               // (key & ~3) | 2
+{
+    int d;
+    asm("v_and_or_b32 %0, %1, -4, 2" : "=v"(d) : "v"(key));
+    return d;
+}
+__device__ __forceinline__ int v_add3_m1(int a, int b)         // a + b - 1
+{
+    int d;
+    asm("v_add3_u32 %0, %1, %2, -1" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int v_pack11(int t, int kterm)      // (t << 11) + kterm, kterm wave-uniform
+{
+    int d;
+    asm("v_lshl_add_u32 %0, %1, 11, %2" : "=v"(d) : "v"(t), "s"(kterm));
+    return d;
+}
+
+template <int R> struct ProfWord;
+template <> struct ProfWord<8> { using T = uint2; };
+template <> struct ProfWord<4> { using T = uint32_t; };
+template <> struct ProfWord<2> { using T = uint16_t; };
+template <> struct ProfWord<1> { using T = uint8_t; };
+
+template <int R>
+__device__ __forceinline__ int prof_byte(const typename ProfWord<R>::T &pw, int r)
+{
+    if constexpr (R == 8) return (int)(int8_t)(((r < 4 ? pw.x : pw.y) >> (8 * (r & 3))) & 0xff);
+    else return (int)(int8_t)(((uint32_t)pw >> (8 * r)) & 0xff);
+}
+
+__device__ __forceinline__ int shr1_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
+
+// Inter-strip hand-off of the single-pair kernel: every boundary cell travels as one naturally aligned 8-byte granule
+// {tag = 1, value = T} written by ONE write-through (sc1) store and polled with sc1 loads -- the data is the flag, no
+// fence (cdna_hip_programming.md G16 "R2"); the buffer is zeroed before every launch so tag 0 = not yet produced.
+__device__ __forceinline__ void granule_store(uint64_t *p, int v)
+{
+    __hip_atomic_store(p, (1ull << 32) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Everything a strip needs that is uniform over the pair.  Passed BY VALUE so that it lives in (scalar) registers.
+struct FastIn {
+    int lane;
+    uint32_t N, M;
+    const uint8_t *q, *t;
+    const int *S;             // LDS, [t][q]
+    uint32_t cols;
+    uint8_t *prof;            // LDS, this wave's profile
+    int nd4, ne4;             // -4*del, -4*ext
+    uint32_t *dirw;
+    int *brow, *brow0;        // boundary row (in place) / copy of strip 0's bottom row from the checkpointed pass
+    uint8_t *advice, *zrow;
+    int *ckpt;
+    bool hazard;
+    int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair
+    uint32_t last_flip;
+    const uint64_t *gin;      // single-pair kernel: granule rows
+    uint64_t *gout;
+    uint32_t *abort_flag;
+};
+
+// The lane's running end-cell candidate (T form) + outcome flags; threaded through the strips by value.
+struct FastOut {
+    int bv;
+    uint32_t by, bx;
+    int corner;
+    bool repaired, brow_bad, aborted;
+};
+
+// a better-than-b for the local end cell, values in any monotone form
+template <int SEM>
+__device__ __forceinline__ bool better_i(int v, uint32_t y, uint32_t x, int bv, uint32_t by, uint32_t bx)
+{
+    if (v > bv) return true;
+    if (v < bv) return false;
+    if (SEM == ALN_CORE_LOCAL) return y < by || (y == by && x < bx);     // first in row-major order (simple/mod.rs:212)
+    return x > bx || (x == bx && y > by);                                 // last in column-major order (aligner_core.rs:224)
+}
+
+template <int SEM, int R, bool SINGLE, bool FIRST>
+struct FastStrip {
+    static constexpr int SPB = 16 / R;
+    static constexpr uint32_t STRIP_ROWS = SINGLE ? 64u * R : (uint32_t)ALN_STRIP_ROWS;
+    static constexpr bool LOCAL = (SEM == ALN_CORE_LOCAL || SEM == ALN_LEGACY_LOCAL);
+    using PW = typename ProfWord<R>::T;
+    const FastIn in;
+    const uint32_t strip;
+    const bool last;
+    const int lane;
+    const uint32_t N;
+    uint32_t lb, rb, yb;
+    bool zsel_on, brow_bad, aborted;
+    int Tl[R], rbv[R];
+    int hdiag, bottom, qoff, inchunk, qchunk, outq;
+    uint32_t advchunk, dw;
+    PW pw;
+    const uint8_t *prow;       // this lane's column of the profile: prof + lane*R
+
+    __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s, bool l)
+        : in(i), strip(s), last(l), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
+
+    // next 64 columns of the row above this strip (T form), one per lane
+    __device__ __forceinline__ int load_boundary(uint32_t xi)
+    {
+        if constexpr (!SINGLE) {
+            return (xi < N) ? in.brow[xi + 1] : 2;
+        } else {
+            const uint64_t *src = in.gin + xi;
+            uint64_t g = 0;
+            uint32_t spins = 0;
+            for (;;) {
+                const bool need = xi < N;
+                if (need) g = granule_load(src);
+                if (__all(!need || (g >> 32) != 0)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if (spins > (1u << 22) ||
+                    ((spins & 1023u) == 0 && __hip_atomic_load(in.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    // the producer never arrived: poison the run instead of hanging the GPU
+                    if (lane == 0) __hip_atomic_store(in.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    aborted = true;
+                    break;
+                }
+            }
+            return (xi < N) ? (int)(uint32_t)g : 2;
+        }
+    }
+
+    template <bool MASKED>
+    __device__ __forceinline__ void step(const uint32_t k)
+    {
+        if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
+            const uint32_t xi = k + (uint32_t)lane;             // 0-based column
+            if (!FIRST) inchunk = load_boundary(xi);
+            if (SEM == ALN_CORE_LOCAL && FIRST && in.hazard) advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
+            qchunk = (xi + 1 < N) ? (int)in.q[xi + 1] * (64 * R) : 0;
+        }
+        const int sel = (int)(k & 63u);
+        int top0;
+        if (FIRST) top0 = LOCAL ? 2 : ((k + 1 == N) ? 2 + (int)(N + 1) * in.nd4 : 2 + (int)(k + 1) * in.nd4);
+        else top0 = __builtin_amdgcn_readlane(inchunk, sel);
+        const int topIn = shr1_i(top0, bottom);                 // lane 0 <- row above the strip, lane l <- lane l-1
+        // cross-lane reads stay in wave-uniform control flow: inside a divergent branch the compiler may compute
+        // their operand for the active lanes only
+        const uint32_t adv = (SEM == ALN_CORE_LOCAL && FIRST) ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, sel) : 0u;
+        const PW pwc = pw;                                      // profile bytes of THIS step (loaded one step ago)
+        qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);   // next step's query code reaches every lane
+        pw = *reinterpret_cast<const PW *>(prow + qoff);
+        // end-cell tie-break term of this step: earlier steps win (core) / later steps win (legacy)
+        const int kterm = (SEM == ALN_CORE_LOCAL) ? (int)(2047u - (k & 2047u)) : (int)(k & 2047u);
+        const uint32_t xm1 = k - (uint32_t)lane;
+        if (!MASKED || xm1 < N) {
+            int top = topIn, diag = hdiag;
+            bool zr = (topIn == 2);                             // "cell above is Beginning" -> penalty del
+            if (SEM == ALN_CORE_LOCAL && FIRST && lane == 0) {
+                // row 1: the carried penalty comes from the bottom cell of the previous column (advice)
+                zr = (k == 0) || (adv != 0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int negp;
+                if (SEM == ALN_CORE_LOCAL) negp = zr ? in.nd4 : in.ne4;
+                else if (SEM == ALN_CORE_GLOBAL) negp = (r == 0 && FIRST && lane == 0 && k == 0) ? in.nd4 : in.ne4;
+                else negp = in.nd4;
+                const int a = top + negp;
+                const int b = v_add3_m1(Tl[r], negp);
+                const int c = diag + prof_byte<R>(pwc, r);
+                int key = v_max3(a, b, c);
+                if (SEM == ALN_LEGACY_LOCAL) key = max(key, 3);
+                const int nt = v_tform(key);
+                int stored = key;
+                if (SEM == ALN_CORE_LOCAL) { zr = (nt == 2); stored = zr ? 3 : key; }
+                dw = __builtin_amdgcn_alignbit((uint32_t)stored, dw, 2);
+                if (LOCAL) rbv[r] = max(rbv[r], v_pack11(nt, kterm));
+                diag = Tl[r];
+                Tl[r] = nt;
+                top = nt;
+            }
+            hdiag = topIn;
+            bottom = Tl[R - 1];
+            if (!SINGLE && !last && lane == 63) {
+                const uint32_t x = xm1 + 1;
+                if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 2) { if (in.brow0[x] != bottom) brow_bad = true; }
+                else {
+                    in.brow[x] = bottom;
+                    if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 1) in.brow0[x] = bottom;
+                }
+            }
+            if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) {
+                int hb = Tl[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Tl[r];
+                in.zrow[xm1 + 1] = (hb == 2) ? 1 : 0;
+            }
+        }
+        if (SINGLE && !last) {
+            // bottom row to the strip below: lane 63's cell of column c = k - 63 enters a 64-deep lane shift register
+            // (DPP wave_shl:1); every 16 columns the newest 16 lanes publish their granules (one 128-B sc1 store)
+            outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);   // lane i <- lane i+1, lane 63 <- bottom
+            const uint32_t c = k - 63u;
+            if (k >= 63u && c < N && ((c & 15u) == 15u || c + 1 == N)) {
+                const uint32_t col = c - 63u + (uint32_t)lane;            // column held by this lane (wraps if < 0)
+                const uint32_t first_new = c & ~15u;
+                if (col >= first_new && col <= c) granule_store(in.gout + col, outq);
+            }
+        }
+    }
+
+    // folds the packed per-row candidates of the 2048-step chunk that starts at step `base` into the lane candidate
+    __device__ __forceinline__ void fold(FastOut &o, uint32_t base)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int v = rbv[r];
+            const uint32_t y = yb + 1 + r;
+            if (v != INT_MIN && y <= in.M) {
+                const int t = v >> 11;
+                const uint32_t kk = (uint32_t)v & 2047u;
+                const uint32_t k = base + ((SEM == ALN_CORE_LOCAL) ? 2047u - kk : kk);
+                const uint32_t x = k - (uint32_t)lane + 1;
+                if (o.bx == 0 || better_i<SEM>(t, y, x, o.bv, o.by, o.bx)) { o.bv = t; o.by = y; o.bx = x; }
+            }
+            rbv[r] = INT_MIN;
+        }
+    }
+
+    // Lane state at a block boundary (direction word flushed, input chunks about to be reloaded): everything the
+    // rest of the strip depends on besides the inputs.  save = store it, !save = "is it identical to the stored one".
+    __device__ __forceinline__ bool checkpoint(uint32_t slot, bool save)
+    {
+        int *base = in.ckpt + slot * (18 * 64) + lane;
+        bool same = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (save) { base[(2 * r) * 64] = Tl[r]; base[(2 * r + 1) * 64] = rbv[r]; }
+            else same = same && base[(2 * r) * 64] == Tl[r] && base[(2 * r + 1) * 64] == rbv[r];
+        }
+        if (save) { base[16 * 64] = hdiag; base[17 * 64] = bottom; }
+        else same = same && base[16 * 64] == hdiag && base[17 * 64] == bottom;
+        return same;
+    }
+
+    __device__ __forceinline__ FastOut run(FastOut o)
+    {
+        const uint32_t M = in.M;
+        const uint32_t y0 = strip * STRIP_ROWS;
+        const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
+        const uint32_t L = (rows + R - 1) / R;
+        const uint32_t nsteps = (SINGLE && !last) ? N + 63 : N + L - 1;
+        yb = y0 + (uint32_t)lane * R;
+        lb = (rows - 1) / R; rb = (rows - 1) % R;
+        zsel_on = (SEM == ALN_CORE_LOCAL) && last && in.hazard;
+        prow = in.prof + lane * R;
+
+        // ---- query profile of this strip's rows: P[c][row] = 4*S[t[row]][c] - 2  (int8), row-contiguous per code
+        int tc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t y = yb + 1 + r;
+            tc[r] = (y <= M) ? (int)in.t[y - 1] * (int)in.cols : 0;
+            // left border H[y][0] in T form (simple/mod.rs:64-70)
+            Tl[r] = LOCAL ? 2 : (y == M ? 2 + (int)(M + 1) * in.nd4 : 2 + (int)y * in.nd4);
+            rbv[r] = INT_MIN;
+        }
+        for (uint32_t c = 0; c < in.cols; ++c) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t bte = (uint32_t)(4 * in.S[tc[r] + c] - 2) & 0xffu;
+                if (r < 4) lo |= bte << (8 * r); else hi |= bte << (8 * (r - 4));
+            }
+            uint8_t *dst = in.prof + c * (64 * R) + lane * R;
+            if constexpr (R == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+            else if constexpr (R == 4) *reinterpret_cast<uint32_t *>(dst) = lo;
+            else if constexpr (R == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)lo;
+            else *dst = (uint8_t)lo;
+        }
+        hdiag = LOCAL || yb == 0 ? 2 : 2 + (int)yb * in.nd4;            // H[yb][0]; yb < M always for valid lanes
+        bottom = Tl[R - 1];
+        inchunk = 2; qchunk = 0; advchunk = 0; dw = 0; outq = 0;
+        qoff = (lane == 0) ? (int)in.q[0] * (64 * R) : 0;
+        pw = *reinterpret_cast<const PW *>(prow + qoff);
+
+        uint32_t *dirw = in.dirw + (size_t)strip * (SINGLE ? (size_t)((N + 63 + SPB - 1) / SPB) * 64u : (size_t)(aln_strip_bytes(N) / 4));
+        const uint32_t nkb = (nsteps + SPB - 1) / SPB;
+        // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
+        const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
+        const uint32_t kb_steady1 = max(kb_steady0, min(nkb, N / SPB));
+        // Segment ends: the 2048-step chunks of the end-cell tracker and, for strip 0 of a hazard pair, the
+        // checkpoint steps 64, 128, 256, 512.
+        const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0;
+        uint32_t next_ck = ckmode ? 64u : 0xffffffffu, slot = 0, chunk_base = 0;
+        uint32_t kb = 0;
+        while (kb < nkb) {
+            uint32_t seg_end = min(nkb, (chunk_base + 2048u) / SPB);
+            if (next_ck != 0xffffffffu) seg_end = min(seg_end, next_ck / SPB);
+            const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
+            for (; kb < e0; ++kb) {
+#pragma unroll
+                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
+                dirw[kb * 64 + lane] = dw;
+            }
+            for (; kb < e1; ++kb) {
+#pragma unroll
+                for (int kk = 0; kk < SPB; ++kk) step<false>(kb * SPB + kk);
+                dirw[kb * 64 + lane] = dw;
+            }
+            for (; kb < seg_end; ++kb) {
+#pragma unroll
+                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
+                dirw[kb * 64 + lane] = dw;
+            }
+            if (ckmode && kb < nkb && kb * SPB == next_ck) {
+                if (in.ck_mode == 1) checkpoint(slot, true);
+                else if (__all(checkpoint(slot, false)) && in.last_flip <= next_ck) {
+                    // every lane is in exactly the state the checkpointed pass had here and no advice differs from
+                    // here on: the rest of this strip -- and so of the whole fill -- is unchanged
+                    o.repaired = true;
+                    o.brow_bad = o.brow_bad || brow_bad;
+                    return o;
+                }
+                ++slot;
+                next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
+            }
+            if (LOCAL && kb * SPB == chunk_base + 2048u) { fold(o, chunk_base); chunk_base += 2048u; }
+        }
+        o.brow_bad = o.brow_bad || brow_bad;
+        o.aborted = o.aborted || aborted;
+        if (ckmode && in.ck_mode == 2) return o;         // ran out of checkpoints: the caller escalates to a full pass
+        if (LOCAL) fold(o, chunk_base);
+        if (last) {
+            int hb = Tl[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Tl[r];
+            o.corner = __builtin_amdgcn_readlane(hb, (int)lb);
+        }
+        return o;
+    }
+};
+
+template <int SEM, bool SINGLE>
+__device__ __forceinline__ FastOut fast_strip(const FastIn &in, FastOut o, uint32_t s, bool last, int R)
+{
+    if (s == 0) {
+        if (R == 8) { FastStrip<SEM, 8, SINGLE, true> f(in, s, last); return f.run(o); }
+        if (R == 4) { FastStrip<SEM, 4, SINGLE, true> f(in, s, last); return f.run(o); }
+        if (R == 2) { FastStrip<SEM, 2, SINGLE, true> f(in, s, last); return f.run(o); }
+        FastStrip<SEM, 1, SINGLE, true> f(in, s, last);
+        return f.run(o);
+    }
+    if (R == 8) { FastStrip<SEM, 8, SINGLE, false> f(in, s, last); return f.run(o); }
+    if (R == 4) { FastStrip<SEM, 4, SINGLE, false> f(in, s, last); return f.run(o); }
+    if (R == 2) { FastStrip<SEM, 2, SINGLE, false> f(in, s, last); return f.run(o); }
+    FastStrip<SEM, 1, SINGLE, false> f(in, s, last);
+    return f.run(o);
+}
+
+// butterfly reduction of the per-lane end-cell candidates with the exact tie rule
+template <int SEM>
+__device__ __forceinline__ void reduce_best(FastOut &o)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int ov = __shfl_xor(o.bv, m);
+        const uint32_t oy = (uint32_t)__shfl_xor((int)o.by, m), ox = (uint32_t)__shfl_xor((int)o.bx, m);
+        if (ox != 0 && (o.bx == 0 || better_i<SEM>(ov, oy, ox, o.bv, o.by, o.bx))) { o.bv = ov; o.by = oy; o.bx = ox; }
+    }
+}

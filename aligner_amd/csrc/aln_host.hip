@@ -294,7 +294,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
     // + 4 checkpoints of strip 0's lane state (26 ints x 64 lanes) and a copy of strip 0's bottom row (fast path)
-    const uint64_t ck_bytes = b->fast ? (4ull * 26 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
+    const uint64_t ck_bytes = b->fast ? (4ull * 18 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
     b->scratch_stride = brow_bytes + 2 * adv_bytes + ck_bytes;
     b->lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
     if (b->fast) { b->prof_stride = cols * 512u; b->lds_bytes += 4u * b->prof_stride; }

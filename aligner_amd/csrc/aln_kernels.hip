@@ -112,21 +112,6 @@ struct Wave {
     // running end-cell candidate of this lane (local semantics) and final corner value (global)
     SC bv; uint32_t by, bx;
     SC corner;
-    // fast integer path only
-    uint8_t *prof;            // LDS: this wave's query profile, cols x 512 bytes
-    int nd4, ne4;             // -4*del, -4*ext
-    // localized repair of the row-1 hazard (batch fast path): checkpoints of strip 0's lane state, a copy of strip 0's
-    // bottom row, the mode of the current strip-0 run and its outcome
-    int *ckpt;                // 4 checkpoints x 26 fields x 64 lanes
-    int *brow0;               // strip 0's bottom row as produced by the checkpointed pass (multi-strip pairs)
-    int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair (compare, stop at the first matching checkpoint)
-    uint32_t last_flip;       // largest column whose advice differs from the checkpointed pass
-    bool repaired, brow_bad;
-    // single-pair kernel only: granule rows in / out, abort word
-    const uint64_t *gin;
-    uint64_t *gout;
-    uint32_t *abort_flag;
-    bool aborted;
 };
 
 // a better-than-b for the local end cell
@@ -301,304 +286,7 @@ __device__ __noinline__ void serial_fill_impl(Wave<SC> &w)
     w.corner = col[M];
 }
 
-// ================================================================= fast integer path
-// Same recurrence, reformulated so that one v_max3 yields value AND direction:
-//   carried state  L = 4*H + 1                      (H exact in the upper 30 bits)
-//   Top  key = Ltop  + 1 - 4p   (tag 2)     Left key = Lleft - 4p (tag 1)     Diag key = Ldiag + (4s - 1) (tag 0)
-//   key = max3(...)  ->  H' = key >> 2,  tag = key & 3 in the reference's tie order Top > Left > Diagonal;
-//   L' = (key & ~3) | 1.   Beginning (H' == 0, local) is tag 3; the legacy clamp at zero is max(key, 3).
-// The substitution scores come from a per-strip query profile in LDS:  P[c][row] = 4*S[t[row]][c] - 1 as int8, so one
-// ds_read of R bytes per step feeds the lane's R cells; the query code travels down the lanes with the same
-// DPP wave_shr:1 that carries the boundary cell.  ~9 VALU ops per cell + ~3 for the local end-cell tracking.
-template <int R> struct ProfWord;
-template <> struct ProfWord<8> { using T = uint2; };
-template <> struct ProfWord<4> { using T = uint32_t; };
-template <> struct ProfWord<2> { using T = uint16_t; };
-template <> struct ProfWord<1> { using T = uint8_t; };
-
-template <int R>
-__device__ __forceinline__ int prof_byte(const typename ProfWord<R>::T &pw, int r)
-{
-    if constexpr (R == 8) return (int)(int8_t)(((r < 4 ? pw.x : pw.y) >> (8 * (r & 3))) & 0xff);
-    else return (int)(int8_t)(((uint32_t)pw >> (8 * r)) & 0xff);
-}
-
-__device__ __forceinline__ int shr1_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
-
-// Inter-strip hand-off of the single-pair kernel: every boundary cell travels as one naturally aligned 8-byte granule
-// {tag = 1, value = L} written by ONE write-through (sc1) store and polled with sc1 loads -- the data is the flag, no
-// fence (cdna_hip_programming.md G16 "R2"); the buffer is zeroed before every launch so tag 0 = not yet produced.
-__device__ __forceinline__ void granule_store(uint64_t *p, int v)
-{
-    __hip_atomic_store(p, (1ull << 32) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int SEM, int R, bool SINGLE, bool FIRST>
-struct FastStrip {
-    static constexpr int SPB = 16 / R;
-    static constexpr uint32_t STRIP_ROWS = SINGLE ? 64u * R : (uint32_t)ALN_STRIP_ROWS;
-    using PW = typename ProfWord<R>::T;
-    Wave<int> &w;
-    const uint32_t strip;
-    const bool last;
-    const int lane;
-    const uint32_t N;
-    uint32_t lb, rb;
-    bool zsel_on;
-    int Ll[R], rbv[R];
-    uint32_t rbx[R];
-    int hdiag, bottom, qoff, inchunk, qchunk, outq;
-    uint32_t advchunk, dw;
-    PW pw;
-    const uint8_t *prow;       // this lane's column of the profile: prof + lane*R
-    int nd4, ne4;
-    // copies of the per-pair fields the inner loop touches (kept out of the Wave object so they stay in registers)
-    const uint8_t *q_;
-    int *brow_, *brow0_;
-    uint8_t *advice_, *zrow_;
-    const uint64_t *gin_;
-    uint64_t *gout_;
-    uint32_t *abort_;
-    bool hazard_, brow_bad_, aborted_;
-    int ck_mode_;
-
-    __device__ __forceinline__ FastStrip(Wave<int> &w_, uint32_t s, bool l)
-        : w(w_), strip(s), last(l), lane(w_.lane), N(w_.N), q_(w_.q), brow_(w_.brow), brow0_(w_.brow0),
-          advice_(w_.advice), zrow_(w_.zrow), gin_(w_.gin), gout_(w_.gout), abort_(w_.abort_flag), hazard_(w_.hazard),
-          brow_bad_(false), aborted_(false), ck_mode_(w_.ck_mode) {}
-
-    // next 64 columns of the row above this strip (L form), one per lane
-    __device__ __forceinline__ int load_boundary(uint32_t xi)
-    {
-        if constexpr (!SINGLE) {
-            return (xi < N) ? brow_[xi + 1] : 1;
-        } else {
-            const uint64_t *src = gin_ + xi;
-            uint64_t g = 0;
-            uint32_t spins = 0;
-            for (;;) {
-                const bool need = xi < N;
-                if (need) g = granule_load(src);
-                if (__all(!need || (g >> 32) != 0)) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22) || (spins & 1023u) == 0 && __hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    // producer never arrived: poison the run instead of hanging the GPU
-                    if (lane == 0) __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    aborted_ = true;
-                    break;
-                }
-            }
-            return (xi < N) ? (int)(uint32_t)g : 1;
-        }
-    }
-
-    template <bool MASKED>
-    __device__ __forceinline__ void step(const uint32_t k)
-    {
-        if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
-            const uint32_t xi = k + (uint32_t)lane;             // 0-based column
-            if (!FIRST) inchunk = load_boundary(xi);
-            if (SEM == ALN_CORE_LOCAL && FIRST && hazard_) advchunk = (xi < N) ? advice_[xi + 1] : 0u;
-            qchunk = (xi + 1 < N) ? (int)q_[xi + 1] * (64 * R) : 0;
-        }
-        const int sel = (int)(k & 63u);
-        int top0;
-        if (FIRST) top0 = is_local<SEM>() ? 1 : ((k + 1 == N) ? 1 + (int)(N + 1) * nd4 : 1 + (int)(k + 1) * nd4);
-        else top0 = __builtin_amdgcn_readlane(inchunk, sel);
-        const int topIn = shr1_i(top0, bottom);                 // lane 0 <- row above the strip, lane l <- lane l-1
-        // cross-lane reads stay in wave-uniform control flow: inside a divergent branch the compiler may compute
-        // their operand for the active lanes only
-        const uint32_t adv = (SEM == ALN_CORE_LOCAL && FIRST) ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, sel) : 0u;
-        const PW pwc = pw;                                      // profile bytes of THIS step (loaded one step ago)
-        qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);   // next step's query code reaches every lane
-        pw = *reinterpret_cast<const PW *>(prow + qoff);
-        const uint32_t xm1 = k - (uint32_t)lane;
-        if (!MASKED || xm1 < N) {
-            const uint32_t x = xm1 + 1;
-            int top = topIn, diag = hdiag;
-            bool zr = (topIn == 1);                             // "cell above is Beginning" -> penalty del
-            if (SEM == ALN_CORE_LOCAL && FIRST && lane == 0) {
-                // row 1: the carried penalty comes from the bottom cell of the previous column (advice)
-                zr = (k == 0) || (adv != 0);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                int negp;
-                if (SEM == ALN_CORE_LOCAL) negp = zr ? nd4 : ne4;
-                else if (SEM == ALN_CORE_GLOBAL) negp = (r == 0 && FIRST && lane == 0 && k == 0) ? nd4 : ne4;
-                else negp = nd4;
-                const int a = top + 1 + negp;
-                const int b = Ll[r] + negp;
-                const int c = diag + prof_byte<R>(pwc, r);
-                int key = max(max(a, b), c);
-                if (SEM == ALN_LEGACY_LOCAL) key = max(key, 3);
-                const int nl = (key & ~3) | 1;
-                int stored = key;
-                if (SEM == ALN_CORE_LOCAL) { zr = (nl == 1); stored = zr ? 3 : key; }
-                dw = __builtin_amdgcn_alignbit((uint32_t)stored, dw, 2);
-                if (is_local<SEM>()) {
-                    const bool upd = (SEM == ALN_CORE_LOCAL) ? (nl > rbv[r]) : (nl >= rbv[r]);
-                    if (upd) { rbv[r] = nl; rbx[r] = x; }
-                }
-                diag = Ll[r];
-                Ll[r] = nl;
-                top = nl;
-            }
-            hdiag = topIn;
-            bottom = Ll[R - 1];
-            if (!SINGLE && !last && lane == 63) {
-                if (FIRST && SEM == ALN_CORE_LOCAL && ck_mode_ == 2) { if (brow0_[x] != bottom) brow_bad_ = true; }
-                else {
-                    brow_[x] = bottom;
-                    if (FIRST && SEM == ALN_CORE_LOCAL && ck_mode_ == 1) brow0_[x] = bottom;
-                }
-            }
-            if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) {
-                int hb = Ll[0];
-#pragma unroll
-                for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Ll[r];
-                zrow_[x] = (hb == 1) ? 1 : 0;
-            }
-        }
-        if (SINGLE && !last) {
-            // bottom row to the strip below: lane 63's cell of column c = k - 63 enters a 64-deep lane shift register
-            // (DPP wave_shl:1); every 16 columns the newest 16 lanes publish their granules (one 128-B sc1 store)
-            outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);   // lane i <- lane i+1, lane 63 <- bottom
-            const uint32_t c = k - 63u;
-            if (k >= 63u && c < N && ((c & 15u) == 15u || c + 1 == N)) {
-                const uint32_t col = c - 63u + (uint32_t)lane;            // column held by this lane (wraps if < 0)
-                const uint32_t first_new = c & ~15u;
-                if (col >= first_new && col <= c) granule_store(gout_ + col, outq);
-            }
-        }
-    }
-
-    // Lane state at a block boundary (direction word flushed, input chunks about to be reloaded): everything the
-    // rest of the strip depends on besides the inputs.  save = store it, !save = "is it identical to the stored one".
-    __device__ __forceinline__ bool checkpoint(uint32_t slot, bool save)
-    {
-        int *base = w.ckpt + slot * (26 * 64) + lane;
-        bool same = true;
-        int f = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (save) { base[(f) * 64] = Ll[r]; base[(f + 1) * 64] = rbv[r]; base[(f + 2) * 64] = (int)rbx[r]; }
-            else same = same && base[f * 64] == Ll[r] && base[(f + 1) * 64] == rbv[r] && base[(f + 2) * 64] == (int)rbx[r];
-            f += 3;
-        }
-        if (save) { base[24 * 64] = hdiag; base[25 * 64] = bottom; }
-        else same = same && base[24 * 64] == hdiag && base[25 * 64] == bottom;
-        return same;
-    }
-
-    __device__ __forceinline__ void run()
-    {
-        const uint32_t M = w.M;
-        const uint32_t y0 = strip * STRIP_ROWS;
-        const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
-        const uint32_t L = (rows + R - 1) / R;
-        const uint32_t nsteps = (SINGLE && !last) ? N + 63 : N + L - 1;
-        const uint32_t yb = y0 + (uint32_t)lane * R;
-        lb = (rows - 1) / R; rb = (rows - 1) % R;
-        zsel_on = (SEM == ALN_CORE_LOCAL) && last && hazard_;
-        nd4 = w.nd4; ne4 = w.ne4;
-        prow = w.prof + lane * R;
-
-        // ---- query profile of this strip's rows: P[c][row] = 4*S[t[row]][c] - 1  (int8), row-contiguous per code
-        int tc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t y = yb + 1 + r;
-            tc[r] = (y <= M) ? (int)w.t[y - 1] * (int)w.cols : 0;
-            // left border H[y][0] in L form (simple/mod.rs:64-70)
-            Ll[r] = is_local<SEM>() ? 1 : (y == M ? 1 + (int)(M + 1) * nd4 : 1 + (int)y * nd4);
-            rbv[r] = (SEM == ALN_LEGACY_LOCAL) ? -3 : INT_MIN;
-            rbx[r] = 0;
-        }
-        for (uint32_t c = 0; c < w.cols; ++c) {
-            uint32_t lo = 0, hi = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t bte = (uint32_t)(4 * w.S[tc[r] + c] - 1) & 0xffu;
-                if (r < 4) lo |= bte << (8 * r); else hi |= bte << (8 * (r - 4));
-            }
-            uint8_t *dst = w.prof + c * (64 * R) + lane * R;
-            if constexpr (R == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
-            else if constexpr (R == 4) *reinterpret_cast<uint32_t *>(dst) = lo;
-            else if constexpr (R == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)lo;
-            else *dst = (uint8_t)lo;
-        }
-        hdiag = is_local<SEM>() || yb == 0 ? 1 : 1 + (int)yb * nd4;     // H[yb][0]; yb < M always for valid lanes
-        bottom = Ll[R - 1];
-        inchunk = 1; qchunk = 0; advchunk = 0; dw = 0; outq = 0;
-        qoff = (lane == 0) ? (int)q_[0] * (64 * R) : 0;
-        pw = *reinterpret_cast<const PW *>(prow + qoff);
-
-        uint32_t *dirw = w.dirw + (size_t)strip * (SINGLE ? (size_t)((N + 63 + SPB - 1) / SPB) * 64u : (size_t)(aln_strip_bytes(N) / 4));
-        const uint32_t nkb = (nsteps + SPB - 1) / SPB;
-        // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
-        const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
-        const uint32_t kb_steady1 = max(kb_steady0, min(nkb, N / SPB));
-        // Strip 0 of a hazard pair runs in segments that end at the checkpoint steps 64, 128, 256, 512.
-        const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && ck_mode_ != 0;
-        uint32_t next_ck = ckmode ? 64u : 0xffffffffu, slot = 0;
-        uint32_t kb = 0;
-        while (kb < nkb) {
-            const uint32_t seg_end = (next_ck == 0xffffffffu) ? nkb : min(nkb, next_ck / SPB);
-            const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
-            for (; kb < e0; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
-                dirw[kb * 64 + lane] = dw;
-            }
-            for (; kb < e1; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < SPB; ++kk) step<false>(kb * SPB + kk);
-                dirw[kb * 64 + lane] = dw;
-            }
-            for (; kb < seg_end; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
-                dirw[kb * 64 + lane] = dw;
-            }
-            if (ckmode && kb < nkb && kb * SPB == next_ck) {
-                if (ck_mode_ == 1) checkpoint(slot, true);
-                else if (__all(checkpoint(slot, false)) && w.last_flip <= next_ck) {
-                    // every lane is in exactly the state the checkpointed pass had here and no advice differs from
-                    // here on: the rest of this strip -- and so of the whole fill -- is unchanged
-                    w.repaired = true;
-                    w.brow_bad = brow_bad_;
-                    return;
-                }
-                ++slot;
-                next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
-            }
-        }
-        w.brow_bad = brow_bad_;
-        w.aborted = w.aborted || aborted_;
-        if (ckmode && ck_mode_ == 2) return;           // ran out of checkpoints: the caller escalates to a full pass
-
-        if (is_local<SEM>()) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t y = yb + 1 + r;
-                if (y <= M && rbx[r] != 0 && better<int, SEM>(rbv[r], y, rbx[r], w.bv, w.by, w.bx)) {
-                    w.bv = rbv[r]; w.by = y; w.bx = rbx[r];
-                }
-            }
-        }
-        if (last) {
-            int hb = Ll[0];
-#pragma unroll
-            for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Ll[r];
-            w.corner = __builtin_amdgcn_readlane(hb, (int)lb);
-        }
-    }
-};
+#include "aln_fast.cuh"
 
 // The per-wave state must stay in registers on the hot path: the out-of-line serial routine gets its own copy so the
 // caller's Wave object never has its address taken.
@@ -612,17 +300,48 @@ __device__ __forceinline__ void serial_fill(Wave<SC> &w)
     w.bv = c.bv; w.by = c.by; w.bx = c.bx; w.corner = c.corner;
 }
 
-template <typename SC, int SEM, int R, bool FAST>
-__device__ __forceinline__ void strip_call(Wave<SC> &w, uint32_t s, bool last)
+// adopts the observed bottom-row zeros as the new row-1 advice; true when nothing changed (self-consistent fill)
+__device__ __forceinline__ bool adopt_advice(uint8_t *advice, const uint8_t *zrow, uint32_t N, int lane, uint32_t &last_flip)
 {
-    if constexpr (FAST) {
-        if (s == 0) { FastStrip<SEM, R, false, true> fs(w, s, last); fs.run(); }
-        else { FastStrip<SEM, R, false, false> fs(w, s, last); fs.run(); }
+    int mismatch = 0;
+    uint32_t lf = 0;
+    for (uint32_t x = 2 + lane; x <= N; x += 64) {
+        const uint8_t z = zrow[x - 1];
+        if (advice[x] != z) { mismatch = 1; advice[x] = z; }
+        if (z != 0) lf = x;                          // advice differs from the all-"ext" first pass here
     }
-    else run_strip<SC, SEM, R>(w, s, last);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) lf = max(lf, (uint32_t)__shfl_xor((int)lf, m));
+    last_flip = lf;
+    __threadfence_block();
+    return !__any(mismatch);
 }
 
-template <typename SC, int SEM, bool FAST>
+// writes the fill-side half of the pair's summary (the traceback kernel adds start cell and length)
+template <int SEM>
+__device__ __forceinline__ void write_result(aln_pair_result &res, double best, uint32_t by, uint32_t bx, double corner,
+                                             uint32_t N, uint32_t M, uint32_t passes, uint32_t flags)
+{
+    res.passes = passes;
+    res.flags = flags;
+    res.start_y = res.start_x = 0;
+    res.aln_len = 0;
+    res.status = ALN_OK;
+    if (is_local<SEM>()) {
+        res.score = best;
+        res.f = best;
+        res.end_y = by; res.end_x = bx;
+        // core local: the argmax runs over the zero borders too; a non-positive maximum sits on (0,0) (simple/mod.rs:212-215)
+        if (SEM == ALN_CORE_LOCAL && !(best > 0.0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
+    } else {
+        res.score = corner;
+        res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : corner;       // simple/mod.rs:139
+        res.end_y = M; res.end_x = N;
+    }
+}
+
+// ---------------------------------------------------------------- one pair, generic kernels (int32 without the profile, f64)
+template <typename SC, int SEM>
 __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair_result &res)
 {
     using O = ScOps<SC>;
@@ -647,75 +366,26 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
     uint32_t passes = 0;
     bool converged = false;
     const uint32_t max_passes = a.max_passes ? a.max_passes : 4u;
-    const uint32_t ns = aln_num_strips(M);
-    // one full fill of every strip with the current advice
-    auto full_pass = [&](int ck_mode) {
-        w.ck_mode = ck_mode;
-        w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)(FAST ? -3 : -1) : O::lowest();
-        w.by = 0; w.bx = 0;
-        for (uint32_t s = 0; s < ns; ++s) {
-            const bool last = (s + 1 == ns);
-            if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
-            const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8;
-            if (R == 8) strip_call<SC, SEM, 8, FAST>(w, s, last);
-            else if (R == 4) strip_call<SC, SEM, 4, FAST>(w, s, last);
-            else if (R == 2) strip_call<SC, SEM, 2, FAST>(w, s, last);
-            else strip_call<SC, SEM, 1, FAST>(w, s, last);
-        }
-        ++passes;
-        __threadfence_block();
-    };
-    // self-consistency: the advice used for row 1 must equal the bottom row the fill produced.  Returns true when it
-    // does; otherwise adopts the observed bottom row as the new advice and reports the largest changed column.
-    auto adopt_advice = [&](uint32_t &last_flip) -> bool {
-        int mismatch = 0;
-        uint32_t lf = 0;
-        for (uint32_t x = 2 + lane; x <= N; x += 64) {
-            const uint8_t z = w.zrow[x - 1];
-            if (w.advice[x] != z) { mismatch = 1; w.advice[x] = z; }
-            if (z != 0) lf = x;                      // advice differs from the all-"ext" first pass here
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) lf = max(lf, (uint32_t)__shfl_xor((int)lf, m));
-        last_flip = lf;
-        __threadfence_block();
-        return !__any(mismatch);
-    };
     if (!a.force_serial) {
-        w.ck_mode = 0; w.repaired = false; w.brow_bad = false; w.last_flip = 0;
-        const bool can_repair = FAST && w.hazard && !a.no_repair;
-        full_pass(can_repair ? 1 : 0);
-        if (!w.hazard) converged = true;
-        else {
-            uint32_t last_flip = 0, repairs = 0;
-            converged = adopt_advice(last_flip);
-            // Localized repair: bottom-row zeros sit next to the left border, so only the first columns of strip 0 see
-            // a different penalty.  Re-run strip 0 with the new advice until its lane state rejoins the checkpointed
-            // first pass; if it never does (or strip 0's bottom row changed) fall back to full passes.
-            if constexpr (FAST && SEM == ALN_CORE_LOCAL) {
-                while (!converged && can_repair && repairs < 8 && last_flip <= 512) {
-                    ++repairs;
-                    w.ck_mode = 2; w.repaired = false; w.brow_bad = false; w.last_flip = last_flip;
-                    const bool last0 = (ns == 1);
-                    const int R0 = last0 ? aln_pick_r(M) : 8;
-                    if (R0 == 8) { FastStrip<SEM, 8, false, true> fs(w, 0, last0); fs.run(); }
-                    else if (R0 == 4) { FastStrip<SEM, 4, false, true> fs(w, 0, last0); fs.run(); }
-                    else if (R0 == 2) { FastStrip<SEM, 2, false, true> fs(w, 0, last0); fs.run(); }
-                    else { FastStrip<SEM, 1, false, true> fs(w, 0, last0); fs.run(); }
-                    __threadfence_block();
-                    passes += 0x100u;                                   // repairs are counted in bits 8..15
-                    if (!__any(w.repaired) || __any(w.brow_bad)) break;  // escalate
-                    if (ns > 1) { converged = true; break; }            // the bottom strip, hence z, is untouched
-                    converged = adopt_advice(last_flip);                // single strip: z may have moved, iterate
-                }
+        const uint32_t ns = aln_num_strips(M);
+        do {
+            w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : O::lowest();
+            w.by = 0; w.bx = 0;
+            for (uint32_t s = 0; s < ns; ++s) {
+                const bool last = (s + 1 == ns);
+                if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
+                const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8;
+                if (R == 8) run_strip<SC, SEM, 8>(w, s, last);
+                else if (R == 4) run_strip<SC, SEM, 4>(w, s, last);
+                else if (R == 2) run_strip<SC, SEM, 2>(w, s, last);
+                else run_strip<SC, SEM, 1>(w, s, last);
             }
-            w.ck_mode = 0;
-            while (!converged && (passes & 0xffu) < max_passes) {
-                full_pass(0);
-                uint32_t lf;
-                converged = adopt_advice(lf);
-            }
-        }
+            ++passes;
+            __threadfence_block();
+            if (!w.hazard) { converged = true; break; }
+            uint32_t lf;
+            converged = adopt_advice(w.advice, w.zrow, N, lane, lf);
+        } while (!converged && passes < max_passes);
     }
     uint32_t layout = ALN_LAYOUT_SKEW;
     if (!converged) {
@@ -728,7 +398,6 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
         layout = ALN_LAYOUT_ROWMAJOR;
         passes |= 0x80u;
     } else if (is_local<SEM>()) {
-        // butterfly reduction of the per-lane candidates
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) {
             const SC ov = O::xshfl(w.bv, m);
@@ -736,36 +405,113 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
             if (ox != 0 && (w.bx == 0 || better<SC, SEM>(ov, oy, ox, w.bv, w.by, w.bx))) { w.bv = ov; w.by = oy; w.bx = ox; }
         }
     }
-    if (FAST && converged) {      // fast path carries L = 4*H + 1
-        w.bv = (SC)((int)w.bv >> 2);
-        w.corner = (SC)((int)w.corner >> 2);
-    }
     if (lane == 0) {
         desc.layout = layout;
-        res.passes = passes;
-        res.flags = sizeof(SC) == 4 ? 1u : 0u;
-        res.start_y = res.start_x = 0;
-        res.aln_len = 0;
-        res.status = ALN_OK;
-        if (is_local<SEM>()) {
-            res.score = (double)w.bv;
-            res.f = (double)w.bv;
-            res.end_y = w.by; res.end_x = w.bx;
-            // core local: the argmax runs over the zero borders too; a non-positive maximum sits on (0,0)
-            if (SEM == ALN_CORE_LOCAL && !(w.bv > (SC)0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
-        } else {
-            res.score = (double)w.corner;
-            res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : (double)w.corner;   // simple/mod.rs:139
-            res.end_y = M; res.end_x = N;
+        write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, N, M, passes, sizeof(SC) == 4 ? 1u : 0u);
+    }
+}
+
+// ---------------------------------------------------------------- one pair, fast integer kernels
+// Core local with del != ext: the fill is speculative in the row-1 penalty ("advice") and exact once the
+// advice equals the bottom row it produced.  Pass 1 runs with all-"ext" advice and checkpoints strip 0; bottom-row zeros
+// sit next to the left border, so a mismatch is repaired by re-running only the leading columns of strip 0 until its
+// lane state rejoins the checkpoint (localized repair); anything else escalates to full re-fills and finally to the
+// strict reference-order routine.
+template <int SEM>
+__device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairDesc &desc, aln_pair_result &res, int del, int ext)
+{
+    const int lane = in.lane;
+    const uint32_t N = desc.N, M = desc.M;
+    in.N = N; in.M = M;
+    in.q = a.seqs + desc.q_off;
+    in.t = a.seqs + desc.t_off;
+    in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
+    in.hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
+    in.ck_mode = 0; in.last_flip = 0;
+    if (in.hazard)
+        for (uint32_t x = lane; x <= N + 1; x += 64) { in.advice[x] = 0; in.zrow[x] = 0; }
+    __threadfence_block();
+
+    const uint32_t ns = aln_num_strips(M);
+    const uint32_t max_passes = a.max_passes ? a.max_passes : 4u;
+    const bool can_repair = in.hazard && !a.no_repair;
+    uint32_t passes = 0;
+    bool converged = false;
+    FastOut o;
+    for (;;) {                                           // full passes
+        o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
+        in.ck_mode = (passes == 0 && can_repair) ? 1 : 0;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const bool last = (s + 1 == ns);
+            if (s > 0) __threadfence_block();            // strip s reads the boundary row strip s-1 stored
+            o = fast_strip<SEM, false>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8);
         }
+        ++passes;
+        __threadfence_block();
+        if (!in.hazard) { converged = true; break; }
+        uint32_t last_flip = 0;
+        converged = adopt_advice(in.advice, in.zrow, N, lane, last_flip);
+        if (converged) break;
+        if (passes == 1 && can_repair) {
+            uint32_t repairs = 0;
+            while (!converged && repairs < 8 && last_flip <= 512) {
+                ++repairs;
+                passes += 0x100u;                        // repairs are counted in bits 8..15
+                in.ck_mode = 2; in.last_flip = last_flip;
+                FastOut ro = o;
+                ro.repaired = false; ro.brow_bad = false;
+                ro = fast_strip<SEM, false>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : 8);
+                __threadfence_block();
+                if (!__any(ro.repaired) || __any(ro.brow_bad)) break;     // escalate to a full pass
+                if (ns > 1) { converged = true; break; }                  // the bottom strip, hence z, is untouched
+                converged = adopt_advice(in.advice, in.zrow, N, lane, last_flip);   // single strip: z may have moved
+            }
+            if (converged) break;
+        }
+        if ((passes & 0xffu) >= max_passes) break;
+    }
+    if (!converged) {                                    // strict reference order (exact for every input)
+        Wave<int> c;
+        c.lane = 0; c.N = N; c.M = M; c.q = in.q; c.t = in.t; c.S = in.S; c.cols = in.cols; c.del = del; c.ext = ext;
+        c.dirw = in.dirw; c.brow = in.brow; c.hmat = nullptr;
+        c.bv = 0; c.by = 0; c.bx = 0; c.corner = 0;
+        if (lane == 0) serial_fill_impl<int, SEM>(c);
+        __threadfence_block();
+        if (lane == 0) {
+            desc.layout = ALN_LAYOUT_ROWMAJOR;
+            write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, 1u);
+        }
+        return;
+    }
+    if (is_local<SEM>()) reduce_best<SEM>(o);
+    if (lane == 0) {
+        desc.layout = ALN_LAYOUT_SKEW;
+        write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)(o.corner >> 2), N, M, passes, 1u);
     }
 }
 
 }  // namespace
 
-// ---------------------------------------------------------------- fill kernel: persistent waves over a work queue
-template <typename SC, int SEM, bool FAST>
-__global__ __launch_bounds__(256, FAST ? 3 : 2) void aln_fill_kernel(FillArgs a)
+// ---------------------------------------------------------------- fill kernels: persistent waves over a work queue
+__device__ __forceinline__ bool next_pair(const FillArgs &a, int lane, uint32_t &pair)
+{
+    uint32_t idx = 0;
+    if (lane == 0) idx = atomicAdd(a.counter, 1u);
+    idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+    if (idx >= a.n_pairs) return false;
+    pair = a.order[idx];
+    return true;
+}
+__device__ __forceinline__ void skip_invalid(aln_pair_result &res, int status, int lane)
+{
+    if (lane == 0) {
+        res.f = 0.0; res.score = 0.0; res.end_y = res.end_x = res.start_y = res.start_x = 0;
+        res.aln_len = 0; res.status = status; res.passes = 0; res.flags = 0;
+    }
+}
+
+template <typename SC, int SEM>
+__global__ __launch_bounds__(256, 2) void aln_fill_kernel(FillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SC *S = reinterpret_cast<SC *>(smem);
@@ -782,37 +528,54 @@ __global__ __launch_bounds__(256, FAST ? 3 : 2) void aln_fill_kernel(FillArgs a)
     w.brow = reinterpret_cast<SC *>(sc);
     w.advice = sc + brow_bytes;
     w.zrow = sc + brow_bytes + adv_bytes;
-    w.ckpt = reinterpret_cast<int *>(sc + brow_bytes + 2 * adv_bytes);
-    w.brow0 = w.ckpt + 4 * 26 * 64;
-    w.ck_mode = 0; w.last_flip = 0; w.repaired = false; w.brow_bad = false;
     w.S = S;
     w.cols = a.cols;
     w.del = ScOps<SC>::from_double(a.del);
     w.ext = ScOps<SC>::from_double(a.ext);
-    const uint32_t mat_bytes = (a.rows * a.cols * (uint32_t)sizeof(SC) + 15u) & ~15u;
-    w.prof = smem + mat_bytes + (threadIdx.x >> 6) * a.prof_stride;
-    w.nd4 = -4 * (int)a.del;
-    w.ne4 = -4 * (int)a.ext;
-
-    for (;;) {
-        uint32_t idx = 0;
-        if (w.lane == 0) idx = atomicAdd(a.counter, 1u);
-        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-        if (idx >= a.n_pairs) break;
-        const uint32_t pair = a.order[idx];
+    uint32_t pair;
+    while (next_pair(a, w.lane, pair)) {
         PairDesc &desc = a.descs[pair];
         aln_pair_result &res = a.results[pair];
-        if (desc.status != ALN_OK) {
-            if (w.lane == 0) {
-                res.f = 0.0; res.score = 0.0; res.end_y = res.end_x = res.start_y = res.start_x = 0;
-                res.aln_len = 0; res.status = desc.status; res.passes = 0; res.flags = 0;
-            }
-            continue;
-        }
-        do_pair<SC, SEM, FAST>(w, a, desc, res);
+        if (desc.status != ALN_OK) { skip_invalid(res, desc.status, w.lane); continue; }
+        do_pair<SC, SEM>(w, a, desc, res);
     }
 }
 
+template <int SEM>
+__global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *S = reinterpret_cast<int *>(smem);
+    const int *gm = reinterpret_cast<const int *>(a.matrix);
+    for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
+    __syncthreads();
+
+    FastIn in;
+    in.lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint8_t *sc = a.scratch + (uint64_t)wave * a.scratch_stride;
+    const uint64_t brow_bytes = ((uint64_t)(a.max_len + 66) * 4 + 63) & ~(uint64_t)63;
+    const uint64_t adv_bytes = ((uint64_t)a.max_len + 66 + 63) & ~(uint64_t)63;
+    in.brow = reinterpret_cast<int *>(sc);
+    in.advice = sc + brow_bytes;
+    in.zrow = sc + brow_bytes + adv_bytes;
+    in.ckpt = reinterpret_cast<int *>(sc + brow_bytes + 2 * adv_bytes);
+    in.brow0 = in.ckpt + 4 * 18 * 64;
+    in.S = S;
+    in.cols = a.cols;
+    in.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u) + (threadIdx.x >> 6) * a.prof_stride;
+    in.nd4 = -4 * (int)a.del;
+    in.ne4 = -4 * (int)a.ext;
+    in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr;
+    in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.ck_mode = 0; in.last_flip = 0;
+    uint32_t pair;
+    while (next_pair(a, in.lane, pair)) {
+        PairDesc &desc = a.descs[pair];
+        aln_pair_result &res = a.results[pair];
+        if (desc.status != ALN_OK) { skip_invalid(res, desc.status, in.lane); continue; }
+        do_pair_fast<SEM>(in, a, desc, res, (int)a.del, (int)a.ext);
+    }
+}
 
 // ---------------------------------------------------------------- single-pair kernel: one wave per strip
 // Grid = number of strips; strip s consumes the granule row strip s-1 publishes 16 columns at a time, so the strips
@@ -828,40 +591,32 @@ __global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
     for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
     __syncthreads();
     const PairDesc &desc = a.descs[a.pair];
-    Wave<int> w;
-    w.lane = threadIdx.x & 63;
-    w.N = desc.N; w.M = desc.M;
-    w.q = a.seqs + desc.q_off;
-    w.t = a.seqs + desc.t_off;
-    w.S = S; w.cols = a.cols;
-    w.del = (int)a.del; w.ext = (int)a.ext;
-    w.nd4 = -4 * (int)a.del; w.ne4 = -4 * (int)a.ext;
-    w.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u);
-    w.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
-    w.brow = nullptr; w.hmat = nullptr;
-    w.advice = a.advice; w.zrow = a.zrow;
-    w.hazard = a.hazard != 0;
-    w.bv = (SEM == ALN_LEGACY_LOCAL) ? -3 : INT_MIN; w.by = 0; w.bx = 0; w.corner = 0;
+    FastIn in;
+    in.lane = threadIdx.x & 63;
+    in.N = desc.N; in.M = desc.M;
+    in.q = a.seqs + desc.q_off;
+    in.t = a.seqs + desc.t_off;
+    in.S = S; in.cols = a.cols;
+    in.nd4 = -4 * (int)a.del; in.ne4 = -4 * (int)a.ext;
+    in.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u);
+    in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
+    in.brow = nullptr; in.brow0 = nullptr; in.ckpt = nullptr;
+    in.advice = a.advice; in.zrow = a.zrow;
+    in.hazard = a.hazard != 0;
+    in.ck_mode = 0; in.last_flip = 0;
     const uint32_t strip = blockIdx.x;
     const bool last = strip + 1 == a.ns;
-    w.gin = a.granules + (uint64_t)(strip ? strip - 1 : 0) * a.gstride;
-    w.gout = a.granules + (uint64_t)strip * a.gstride;
-    w.abort_flag = a.ctrl;
-    w.aborted = false;
-    w.ckpt = nullptr; w.brow0 = nullptr; w.ck_mode = 0; w.last_flip = 0; w.repaired = false; w.brow_bad = false;
-    if (strip == 0) { FastStrip<SEM, R, true, true> fs(w, strip, last); fs.run(); }
-    else { FastStrip<SEM, R, true, false> fs(w, strip, last); fs.run(); }
-    if (is_local<SEM>()) {
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const int ov = __shfl_xor(w.bv, m);
-            const uint32_t oy = (uint32_t)__shfl_xor((int)w.by, m), ox = (uint32_t)__shfl_xor((int)w.bx, m);
-            if (ox != 0 && (w.bx == 0 || better<int, SEM>(ov, oy, ox, w.bv, w.by, w.bx))) { w.bv = ov; w.by = oy; w.bx = ox; }
-        }
-    }
-    if (w.lane == 0) {
+    in.gin = a.granules + (uint64_t)(strip ? strip - 1 : 0) * a.gstride;
+    in.gout = a.granules + (uint64_t)strip * a.gstride;
+    in.abort_flag = a.ctrl;
+    FastOut o;
+    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
+    if (strip == 0) { FastStrip<SEM, R, true, true> fs(in, strip, last); o = fs.run(o); }
+    else { FastStrip<SEM, R, true, false> fs(in, strip, last); o = fs.run(o); }
+    if (is_local<SEM>()) reduce_best<SEM>(o);
+    if (in.lane == 0) {
         int32_t *c = a.cand + 4 * strip;
-        c[0] = w.bv; c[1] = (int32_t)w.by; c[2] = (int32_t)w.bx; c[3] = w.corner;
+        c[0] = o.bv; c[1] = (int32_t)o.by; c[2] = (int32_t)o.bx; c[3] = o.corner;
     }
 }
 
@@ -875,18 +630,15 @@ __global__ __launch_bounds__(64) void aln_single_finalize_kernel(SingleArgs a)
     PairDesc &desc = a.descs[a.pair];
     aln_pair_result &res = a.results[a.pair];
     const uint32_t N = desc.N, M = desc.M;
-    int bv = (SEM == ALN_LEGACY_LOCAL) ? -3 : INT_MIN;
-    uint32_t by = 0, bx = 0;
+    FastOut o;
+    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
     for (uint32_t s = lane; s < a.ns; s += 64) {
         const int32_t *c = a.cand + 4 * s;
-        if (c[2] != 0 && (bx == 0 || better<int, SEM>(c[0], (uint32_t)c[1], (uint32_t)c[2], bv, by, bx))) { bv = c[0]; by = c[1]; bx = c[2]; }
+        if (c[2] != 0 && (o.bx == 0 || better_i<SEM>(c[0], (uint32_t)c[1], (uint32_t)c[2], o.bv, o.by, o.bx))) { o.bv = c[0]; o.by = c[1]; o.bx = c[2]; }
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int ov = __shfl_xor(bv, m);
-        const uint32_t oy = (uint32_t)__shfl_xor((int)by, m), ox = (uint32_t)__shfl_xor((int)bx, m);
-        if (ox != 0 && (bx == 0 || better<int, SEM>(ov, oy, ox, bv, by, bx))) { bv = ov; by = oy; bx = ox; }
-    }
+    reduce_best<SEM>(o);
+    const int bv = o.bv;
+    const uint32_t by = o.by, bx = o.bx;
     int mismatch = 0;
     if (a.hazard) for (uint32_t x = 2 + lane; x <= N; x += 64) mismatch |= (a.advice[x] != a.zrow[x - 1]);
     const bool again = __any(mismatch);
@@ -902,19 +654,8 @@ __global__ __launch_bounds__(64) void aln_single_finalize_kernel(SingleArgs a)
     if (lane == 0) {
         const int corner = a.cand[4 * (a.ns - 1) + 3] >> 2;
         desc.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
-        res.passes = a.pass + 1; res.flags = 1u;
-        res.start_y = res.start_x = 0; res.aln_len = 0;
-        res.status = aborted ? ALN_ERR_DEVICE : ALN_OK;
-        if (is_local<SEM>()) {
-            const int v = bv >> 2;
-            res.score = res.f = (double)v;
-            res.end_y = by; res.end_x = bx;
-            if (SEM == ALN_CORE_LOCAL && !(v > 0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
-        } else {
-            res.score = (double)corner;
-            res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : (double)corner;
-            res.end_y = M; res.end_x = N;
-        }
+        write_result<SEM>(res, (double)(bv >> 2), by, bx, (double)corner, N, M, a.pass + 1, 1u);
+        if (aborted) res.status = ALN_ERR_DEVICE;
     }
 }
 
@@ -940,15 +681,7 @@ __global__ __launch_bounds__(64) void aln_single_serial_kernel(SingleArgs a)
     w.hmat = nullptr;
     serial_fill_impl<int, SEM>(w);
     desc.layout = ALN_LAYOUT_ROWMAJOR;
-    res.passes = a.ctrl[15] | 0x80u; res.flags = 1u;
-    res.start_y = res.start_x = 0; res.aln_len = 0; res.status = ALN_OK;
-    if (is_local<SEM>()) {
-        res.score = res.f = (double)w.bv; res.end_y = w.by; res.end_x = w.bx;
-        if (SEM == ALN_CORE_LOCAL && !(w.bv > 0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
-    } else {
-        res.score = (double)w.corner; res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : (double)w.corner;
-        res.end_y = desc.M; res.end_x = desc.N;
-    }
+    write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, desc.N, desc.M, a.ctrl[15] | 0x80u, 1u);
 }
 
 // arms pass 0 and clears the advice / bottom-row bytes
@@ -1092,25 +825,27 @@ extern "C" __global__ void aln_unpack_directions_kernel(const uint8_t *dirs, con
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), b(256);
-#define ALN_LAUNCH(SC, SEM, FAST) hipLaunchKernelGGL((aln_fill_kernel<SC, SEM, FAST>), g, b, lds_bytes, s, *a)
+#define ALN_LAUNCH(SC, SEM) hipLaunchKernelGGL((aln_fill_kernel<SC, SEM>), g, b, lds_bytes, s, *a)
+#define ALN_LAUNCH_FAST(SEM) hipLaunchKernelGGL((aln_fill_fast_kernel<SEM>), g, b, lds_bytes, s, *a)
     if (is_int && fast) {
         switch (a->semantics) {
-        case ALN_CORE_GLOBAL: ALN_LAUNCH(int, ALN_CORE_GLOBAL, true); break;
-        case ALN_CORE_LOCAL: ALN_LAUNCH(int, ALN_CORE_LOCAL, true); break;
-        case ALN_LEGACY_GLOBAL: ALN_LAUNCH(int, ALN_LEGACY_GLOBAL, true); break;
-        default: ALN_LAUNCH(int, ALN_LEGACY_LOCAL, true); break;
+        case ALN_CORE_GLOBAL: ALN_LAUNCH_FAST(ALN_CORE_GLOBAL); break;
+        case ALN_CORE_LOCAL: ALN_LAUNCH_FAST(ALN_CORE_LOCAL); break;
+        case ALN_LEGACY_GLOBAL: ALN_LAUNCH_FAST(ALN_LEGACY_GLOBAL); break;
+        default: ALN_LAUNCH_FAST(ALN_LEGACY_LOCAL); break;
         }
     } else if (is_int) {
         switch (a->semantics) {
-        case ALN_CORE_GLOBAL: ALN_LAUNCH(int, ALN_CORE_GLOBAL, false); break;
-        case ALN_CORE_LOCAL: ALN_LAUNCH(int, ALN_CORE_LOCAL, false); break;
-        case ALN_LEGACY_GLOBAL: ALN_LAUNCH(int, ALN_LEGACY_GLOBAL, false); break;
-        default: ALN_LAUNCH(int, ALN_LEGACY_LOCAL, false); break;
+        case ALN_CORE_GLOBAL: ALN_LAUNCH(int, ALN_CORE_GLOBAL); break;
+        case ALN_CORE_LOCAL: ALN_LAUNCH(int, ALN_CORE_LOCAL); break;
+        case ALN_LEGACY_GLOBAL: ALN_LAUNCH(int, ALN_LEGACY_GLOBAL); break;
+        default: ALN_LAUNCH(int, ALN_LEGACY_LOCAL); break;
         }
     } else {
-        if (a->semantics == ALN_CORE_GLOBAL) ALN_LAUNCH(double, ALN_CORE_GLOBAL, false);
-        else ALN_LAUNCH(double, ALN_CORE_LOCAL, false);
+        if (a->semantics == ALN_CORE_GLOBAL) ALN_LAUNCH(double, ALN_CORE_GLOBAL);
+        else ALN_LAUNCH(double, ALN_CORE_LOCAL);
     }
+#undef ALN_LAUNCH_FAST
 #undef ALN_LAUNCH
 }
 extern "C" void aln_launch_single(const SingleArgs *a, uint32_t lds_bytes, int with_serial, hipStream_t s)
