@@ -8,11 +8,14 @@
 //               strip s = rows s*512+1 .. (s+1)*512 of H, handled by one wave; lane l owns R consecutive rows
 //               (R = 8 for every full strip; the last strip picks the smallest R in {1,2,4,8} covering its rows);
 //               lane l computes column x at wave step k = (x-1) + l (anti-diagonal skew);
-//               one u32 per lane holds R rows x (16/R) consecutive steps: word index = (k / SPB) * 64 + lane,
-//               SPB = 16/R.  Cells are shifted in from the top (v_alignbit), so the cell of (row r, step k) sits
-//               at bits 30 - 2*((e - k)*R + (R-1-r)), e = last step of that block in which the lane is active
-//               (aln_dir_bitpos).  A wave therefore stores 256 contiguous bytes per SPB steps -- fully coalesced,
-//               0.25 B per cell.  The 2-bit value is the priority tag of the max: 0 Diagonal, 1 Left, 2 Top,
+//               one u32 per lane holds R rows x SPB = 16/R consecutive steps (a "block"); a lane keeps FOUR blocks
+//               in registers and stores them as one 16-byte quad: word index of step k =
+//               ((kb >> 2) * 64 + lane) * 4 + (kb & 3), kb = k / SPB (aln_dir_word_index).  A wave therefore stores
+//               1 KiB contiguous per 4*SPB steps (global_store_dwordx4, fully coalesced, 0.25 B per cell) and one
+//               128-byte line holds 8 lanes x 4 blocks, i.e. a 64-row x 8..64-step tile -- the traceback walk stays
+//               inside a line for several steps.  Cells are shifted in from the top (v_alignbit), so the cell of
+//               (row r, step k) sits at bits 30 - 2*((e - k)*R + (R-1-r)), e = last step of that block in which the
+//               lane is active (aln_dir_bitpos).  The 2-bit value is the priority tag of the max: 0 Diagonal, 1 Left, 2 Top,
 //               3 Beginning (aln_tag_to_dir maps it to the reference's Direction discriminant).
 //             serial-order fallback (layout 1): plain row-major, row stride (N+4)/4 bytes, 4 cells per byte.
 //   results : aln_pair_result[n]
@@ -110,8 +113,18 @@ __host__ __device__ inline int aln_pick_r(uint32_t rem)
     return rem > 256 ? 8 : rem > 128 ? 4 : rem > 64 ? 2 : 1;
 }
 __host__ __device__ inline uint32_t aln_num_strips(uint32_t M) { return (M + ALN_STRIP_ROWS - 1) / ALN_STRIP_ROWS; }
-// bytes of one full (R = 8) strip region: steps N+63, 2 steps per word, 64 words (256 B) per block
-__host__ __device__ inline uint64_t aln_strip_bytes(uint32_t N) { return (uint64_t)((N + 63 + 1) / 2) * 256u; }
+// blocks (of SPB steps) a strip of `nsteps` steps stores, padded to whole quads
+__host__ __device__ inline uint32_t aln_strip_blocks(uint32_t nsteps, uint32_t spb) { return (((nsteps + spb - 1) / spb) + 3u) & ~3u; }
+// word index of wave step k of lane `lane` inside its strip region
+__host__ __device__ inline uint64_t aln_dir_word_index(uint32_t k, uint32_t lane, uint32_t spb)
+{
+    const uint32_t kb = k / spb;
+    return ((uint64_t)(kb >> 2) * 64u + lane) * 4u + (kb & 3u);
+}
+// bytes of one full (R = 8) strip region: steps N+63, 2 steps per block, 256 B per block
+__host__ __device__ inline uint64_t aln_strip_bytes(uint32_t N) { return (uint64_t)aln_strip_blocks(N + 63, 2) * 256u; }
+// bytes of one strip of the uniform-R layout (single-pair kernel)
+__host__ __device__ inline uint64_t aln_uniform_strip_bytes(uint32_t N, uint32_t R) { return (uint64_t)aln_strip_blocks(N + 63, 16u / R) * 256u; }
 __host__ __device__ inline uint64_t aln_rowmajor_bytes(uint32_t N, uint32_t M)
 {
     return (uint64_t)(M + 1) * ((N + 4) / 4);

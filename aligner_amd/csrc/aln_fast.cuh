@@ -236,6 +236,24 @@ struct FastStrip {
         }
     }
 
+    // four blocks of SPB steps -> one 16-byte store per lane (1 KiB per wave, coalesced).  The block loop is a real
+    // loop (not unrolled): unrolling 4*SPB steps makes the scheduler hoist every step's uniform values and spill.
+    template <bool MASKED>
+    __device__ __forceinline__ void quad(uint4 *dirq, const uint32_t kb)
+    {
+        uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+        for (uint32_t j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int kk = 0; kk < SPB; ++kk) step<MASKED>((kb + j) * SPB + kk);
+            if (j == 0) v.x = dw;
+            else if (j == 1) v.y = dw;
+            else if (j == 2) v.z = dw;
+            else v.w = dw;
+        }
+        dirq[(size_t)(kb >> 2) * 64] = v;
+    }
+
     // folds the packed per-row candidates of the 2048-step chunk that starts at step `base` into the lane candidate
     __device__ __forceinline__ void fold(FastOut &o, uint32_t base)
     {
@@ -311,11 +329,13 @@ struct FastStrip {
         qoff = (lane == 0) ? (int)in.q[0] * (64 * R) : 0;
         pw = *reinterpret_cast<const PW *>(prow + qoff);
 
-        uint32_t *dirw = in.dirw + (size_t)strip * (SINGLE ? (size_t)((N + 63 + SPB - 1) / SPB) * 64u : (size_t)(aln_strip_bytes(N) / 4));
-        const uint32_t nkb = (nsteps + SPB - 1) / SPB;
+        // directions: four blocks per lane per 16-byte store (aln_device.h); all segment ends are whole quads
+        uint4 *dirq = reinterpret_cast<uint4 *>(in.dirw) +
+                      (size_t)strip * (SINGLE ? (size_t)(aln_uniform_strip_bytes(N, R) / 16) : (size_t)(aln_strip_bytes(N) / 16)) + lane;
+        const uint32_t nkb = aln_strip_blocks(nsteps, SPB);
         // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
         const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
-        const uint32_t kb_steady1 = max(kb_steady0, min(nkb, N / SPB));
+        const uint32_t kb_steady1 = max(kb_steady0, min(nkb, (N / (4 * SPB)) * 4u));
         // Segment ends: the 2048-step chunks of the end-cell tracker and, for strip 0 of a hazard pair, the
         // checkpoint steps 64, 128, 256, 512.
         const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0;
@@ -325,21 +345,9 @@ struct FastStrip {
             uint32_t seg_end = min(nkb, (chunk_base + 2048u) / SPB);
             if (next_ck != 0xffffffffu) seg_end = min(seg_end, next_ck / SPB);
             const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
-            for (; kb < e0; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
-                dirw[kb * 64 + lane] = dw;
-            }
-            for (; kb < e1; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < SPB; ++kk) step<false>(kb * SPB + kk);
-                dirw[kb * 64 + lane] = dw;
-            }
-            for (; kb < seg_end; ++kb) {
-#pragma unroll
-                for (int kk = 0; kk < SPB; ++kk) step<true>(kb * SPB + kk);
-                dirw[kb * 64 + lane] = dw;
-            }
+            for (; kb < e0; kb += 4) quad<true>(dirq, kb);
+            for (; kb < e1; kb += 4) quad<false>(dirq, kb);
+            for (; kb < seg_end; kb += 4) quad<true>(dirq, kb);
             if (ckmode && kb < nkb && kb * SPB == next_ck) {
                 if (in.ck_mode == 1) checkpoint(slot, true);
                 else if (__all(checkpoint(slot, false)) && in.last_flip <= next_ck) {

@@ -256,7 +256,8 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
             if ((d.M + 64 * R - 1) / (64 * R) > 4096) single = false;
             if (single) {
                 const uint32_t ns = (d.M + 64 * R - 1) / (64 * R), spb = 16 / R;
-                dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * ((d.N + 63 + spb - 1) / spb) * 256u);
+                dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * aln_uniform_strip_bytes(d.N, R));
+                (void)spb;
                 b->single_pairs.push_back((uint32_t)i);
                 b->single_r.push_back(R);
                 const uint64_t gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
@@ -490,7 +491,7 @@ extern "C" uint64_t aln_batch_direction_bytes(const aln_batch *b)
             const uint32_t rem = d.M - s * ALN_STRIP_ROWS;
             const int R = last ? aln_pick_r(rem) : 8;
             const uint32_t rows = std::min<uint32_t>(rem, 64u * R), L = (rows + R - 1) / R, spb = 16 / R;
-            total += (uint64_t)((d.N + L - 1 + spb - 1) / spb) * 256u;
+            total += (uint64_t)aln_strip_blocks(d.N + L - 1, spb) * 256u;
         }
     }
     return total;

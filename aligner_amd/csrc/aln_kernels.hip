@@ -222,7 +222,7 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
                 }
             }
         }
-        dirw[kb * 64 + lane] = dw;                     // 256 B per wave, coalesced
+        dirw[aln_dir_word_index(kb * SPB, (uint32_t)lane, SPB)] = dw;   // quad layout of the fast path (aln_device.h)
     }
 
     // fold this strip's per-row candidates into the lane's running end-cell candidate
@@ -712,7 +712,7 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
         R = (int)((d.layout >> 8) & 0xffu);
         strip = (y - 1) / (64u * R);
         i = (y - 1) - strip * 64u * R;
-        strip_bytes = (uint64_t)((d.N + 63 + 16 / R - 1) / (16 / R)) * 256u;
+        strip_bytes = aln_uniform_strip_bytes(d.N, (uint32_t)R);
     } else {
         strip = (y - 1) / ALN_STRIP_ROWS;
         const uint32_t ns = aln_num_strips(d.M);
@@ -724,7 +724,7 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
     const uint32_t k = (x - 1) + lane;
     const uint32_t spb = 16 / R;
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * strip_bytes);
-    const uint32_t word = wbase[(k / spb) * 64 + lane];
+    const uint32_t word = wbase[aln_dir_word_index(k, lane, spb)];
     return aln_tag_to_dir((int)((word >> aln_dir_bitpos(k, r, lane, d.N, R)) & 3u));
 }
 
@@ -743,7 +743,7 @@ __device__ __forceinline__ uint32_t dir_prefetch(const uint8_t *dirs, const Pair
         R = (int)((d.layout >> 8) & 0xffu);
         strip = (y - 1) / (64u * R);
         i = (y - 1) - strip * 64u * R;
-        strip_bytes = (uint64_t)((d.N + 63 + 16 / R - 1) / (16 / R)) * 256u;
+        strip_bytes = aln_uniform_strip_bytes(d.N, (uint32_t)R);
     } else {
         strip = (y - 1) / ALN_STRIP_ROWS;
         const uint32_t ns = aln_num_strips(d.M);
@@ -754,17 +754,17 @@ __device__ __forceinline__ uint32_t dir_prefetch(const uint8_t *dirs, const Pair
     const uint32_t lane = i / R, spb = 16u / R;
     const uint32_t kb = ((x - 1) + lane) / spb;
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * strip_bytes);
-    const uint32_t J = 16u / spb + 1u;                   // blocks covered by 16 steps
-    const uint32_t drift = (spb + R - 1) / R;            // lanes the path can climb per block
+    // a quad (4 blocks x 16 B) per lane, 8 lanes per 128-byte line: touch the current and the next two quads of
+    // this lane's line and of the line above it
+    const uint32_t kq = kb >> 2;
     uint32_t v[18];
 #pragma unroll
     for (uint32_t j = 0; j < 9; ++j) {
-        const uint32_t jj = j < J ? j : J;
-        const uint32_t b = kb >= jj ? kb - jj : 0;
-        const uint32_t la = lane >= jj * drift / 2 ? lane - jj * drift / 2 : 0;
-        const uint32_t lb = la >= 12 ? la - 12 : 0;
-        v[2 * j] = wbase[b * 64 + la];
-        v[2 * j + 1] = wbase[b * 64 + lb];
+        const uint32_t jj = j % 3, up = j / 3;
+        const uint32_t b = kq >= jj ? kq - jj : 0;
+        const uint32_t la = lane >= up * 8 ? lane - up * 8 : 0;
+        v[2 * j] = wbase[((uint64_t)b * 64 + la) * 4];
+        v[2 * j + 1] = wbase[((uint64_t)b * 64 + la) * 4 + 3];
     }
     uint32_t acc = 0;
 #pragma unroll
