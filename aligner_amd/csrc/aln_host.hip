@@ -268,7 +268,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
         d.dir_off = dir_total;
         dir_total += dbytes;
         d.tb_off = tb_total;
-        tb_total += 2ull * ((uint64_t)d.N + d.M + 2);
+        tb_total += 3ull * ((uint64_t)d.N + d.M + 2);   // aligned query, aligned target, traceback tag scratch
         if (want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
     }
     b->dir_bytes = dir_total;

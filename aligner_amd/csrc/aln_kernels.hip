@@ -772,8 +772,37 @@ __device__ __forceinline__ uint32_t dir_prefetch(const uint8_t *dirs, const Pair
     return acc;
 }
 
+// Per-strip constants of the packed direction store, re-derived only when the walk leaves the strip.
+struct StripView {
+    const uint32_t *wbase;
+    uint32_t y0;        // rows of the strip are y0+1 .. y0+rows
+    uint32_t lgR;       // log2(rows per lane)
+};
+__device__ __forceinline__ StripView strip_view(const uint8_t *dirs, const PairDesc &d, uint32_t y)
+{
+    StripView v;
+    const uint8_t *base = dirs + d.dir_off;
+    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) {
+        const uint32_t R = (d.layout >> 8) & 0xffu;
+        v.lgR = 31u - (uint32_t)__builtin_clz(R);
+        const uint32_t strip = (y - 1) >> (6 + v.lgR);
+        v.y0 = strip << (6 + v.lgR);
+        v.wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_uniform_strip_bytes(d.N, R));
+    } else {
+        const uint32_t strip = (y - 1) / ALN_STRIP_ROWS;
+        const uint32_t ns = aln_num_strips(d.M);
+        const uint32_t R = (strip + 1 == ns) ? (uint32_t)aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8u;
+        v.lgR = 31u - (uint32_t)__builtin_clz(R);
+        v.y0 = strip * ALN_STRIP_ROWS;
+        v.wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_strip_bytes(d.N));
+    }
+    return v;
+}
+
 // One thread per pair: the reference's pointer chase (simple/mod.rs:99-130, :213-245; legacy :146-176, :232-261),
-// including the duplicated seed pair.  Strings are written back to front, then reversed in place.
+// including the duplicated seed pair.  Pass 1 is the dependent chain -- one direction word per step, shifts only, the
+// 2-bit tags go to a scratch byte string; pass 2 turns the tags into the two aligned code strings, written in final
+// (forward) order, with loads whose addresses do not depend on loaded data.
 extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs a)
 {
     const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -781,31 +810,93 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     const PairDesc &d = a.descs[pair];
     aln_pair_result &res = a.results[pair];
     if (res.status != ALN_OK) return;
-    const uint8_t *q = a.seqs + d.q_off, *t = a.seqs + d.t_off;
-    uint8_t *qa = a.tb + d.tb_off, *ta = qa + (d.N + d.M + 2);
+    const uint8_t *__restrict__ q = a.seqs + d.q_off;
+    const uint8_t *__restrict__ t = a.seqs + d.t_off;
+    const uint32_t cap = d.N + d.M + 2;
+    uint8_t *__restrict__ qa = a.tb + d.tb_off;
+    uint8_t *__restrict__ ta = qa + cap;
+    uint8_t *__restrict__ ops = ta + cap;
     const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
     const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
-    uint32_t cy = res.end_y, cx = res.end_x;
-    qa[0] = q[cx - 1];
-    ta[0] = t[cy - 1];
+    const uint32_t ey = res.end_y, ex = res.end_x, N = d.N;
+    uint32_t cy = ey, cx = ex;
     if (legacy) { cy -= 1; cx -= 1; }   // legacy starts at the diagonal predecessor (aligner_core.rs:146-147, :232-233)
-    uint32_t len = 1, keep = 0;
-    for (;;) {
-        if ((len & 15u) == 1u) keep |= dir_prefetch(a.dirs, d, cy, cx);
-        const int dd = dir_at(a.dirs, d, global, cy, cx);
-        if (dd == D_BEG) break;
-        if (dd == D_TOP) { qa[len] = a.blank; ta[len] = t[cy - 1]; cy--; }
-        else if (dd == D_LEFT) { qa[len] = q[cx - 1]; ta[len] = a.blank; cx--; }
-        else { qa[len] = q[cx - 1]; ta[len] = t[cy - 1]; cx--; cy--; }
-        len++;
-    }
-    for (uint32_t i = 0, j = len - 1; i < j; ++i, --j) {
-        uint8_t u = qa[i]; qa[i] = qa[j]; qa[j] = u;
-        u = ta[i]; ta[i] = ta[j]; ta[j] = u;
+    uint32_t len = 0;                   // steps taken (the seed pair is added in pass 2)
+    if (d.layout == ALN_LAYOUT_ROWMAJOR) {
+        for (;;) {
+            const int dd = dir_at(a.dirs, d, global, cy, cx);
+            if (dd == D_BEG) break;
+            ops[len++] = (uint8_t)aln_dir_to_tag(dd);
+            cy -= (dd != D_LEFT); cx -= (dd != D_TOP);
+        }
+    } else {
+        StripView sv = strip_view(a.dirs, d, cy != 0 ? cy : 1u);
+        while (cy != 0 && cx != 0) {
+            if (cy - 1 - sv.y0 >= (64u << sv.lgR)) sv = strip_view(a.dirs, d, cy);   // the walk left the strip (upwards)
+            const uint32_t i = cy - 1 - sv.y0, lgR = sv.lgR, R = 1u << lgR, sh = 4u - lgR;
+            const uint32_t lane = i >> lgR, r = i & (R - 1u);
+            const uint32_t k = cx - 1 + lane, kb = k >> sh;
+            const uint32_t word = sv.wbase[(((uint64_t)(kb >> 2) * 64u + lane) << 2) + (kb & 3u)];
+            const uint32_t bend = (kb << sh) + (1u << sh) - 1u, lend = lane + N - 1u;
+            const uint32_t e = min(bend, lend);
+            const uint32_t tag = (word >> (30u - 2u * (((e - k) << lgR) + (R - 1u - r)))) & 3u;
+            if (tag == 3u) break;                       // Beginning
+            ops[len++] = (uint8_t)tag;
+            cy -= (tag != 1u); cx -= (tag != 2u);       // 0 Diagonal, 1 Left, 2 Top
+        }
+        if (global) {                                   // borders: D[0][x] = Left, D[y][0] = Top (simple/mod.rs:59-67)
+            while (cx != 0 && cy == 0) { ops[len++] = 1; cx--; }
+            while (cy != 0 && cx == 0) { ops[len++] = 2; cy--; }
+        }
     }
     res.start_y = cy; res.start_x = cx;
-    res.aln_len = len;
-    if (keep == 0x9e3779b9u && len == 0xffffffffu) res.flags |= 0x80000000u;   // never true: keeps the look-ahead loads
+    res.aln_len = len + 1;                              // + the duplicated seed pair, written by the expand kernel
+}
+
+// Pass 2, one wave per pair: turns the tag string into the two aligned code strings in final (forward) order.
+// Position j of the output is step (len - 1 - j); its cell is the stop cell plus the moves of the steps after it, i.e.
+// a prefix sum over the tags -- each lane sums its contiguous slice, one wave scan, then each lane replays its slice.
+extern "C" __global__ __launch_bounds__(256) void aln_traceback_expand_kernel(TraceArgs a)
+{
+    const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= a.n_pairs) return;
+    const int lane = threadIdx.x & 63;
+    const PairDesc &d = a.descs[pair];
+    const aln_pair_result &res = a.results[pair];
+    if (res.status != ALN_OK) return;
+    const uint8_t *__restrict__ q = a.seqs + d.q_off;
+    const uint8_t *__restrict__ t = a.seqs + d.t_off;
+    const uint32_t cap = d.N + d.M + 2;
+    uint8_t *__restrict__ qa = a.tb + d.tb_off;
+    uint8_t *__restrict__ ta = qa + cap;
+    const uint8_t *__restrict__ ops = ta + cap;
+    const uint32_t len = res.aln_len - 1;
+    // output positions j in [lo, hi) belong to this lane; position j reads ops[len - 1 - j]
+    const uint32_t per = (len + 63) / 64;
+    const uint32_t lo = min(len, (uint32_t)lane * per), hi = min(len, lo + per);
+    uint32_t dy = 0, dx = 0;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t tag = ops[len - 1 - j];
+        dx += (tag != 2u); dy += (tag != 1u);
+    }
+    // exclusive wave scan of (dy, dx)
+    uint32_t sy = dy, sx = dx;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t oy = (uint32_t)__shfl_up((int)sy, m), ox = (uint32_t)__shfl_up((int)sx, m);
+        if (lane >= m) { sy += oy; sx += ox; }
+    }
+    uint32_t py = res.start_y + sy - dy, px = res.start_x + sx - dx;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t tag = ops[len - 1 - j];
+        px += (tag != 2u); py += (tag != 1u);           // the cell this step left
+        qa[j] = (tag == 2u) ? a.blank : q[px - 1];
+        ta[j] = (tag == 1u) ? a.blank : t[py - 1];
+    }
+    if (lane == 0) {
+        qa[len] = q[res.end_x - 1];                     // simple/mod.rs:102-105, :213-216: the duplicated seed
+        ta[len] = t[res.end_y - 1];
+    }
 }
 
 // (M+1)x(N+1) Direction bytes for one pair = AlignmentResult.direction_matrix
@@ -876,6 +967,7 @@ extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
 {
     const uint32_t grid = (a->n_pairs + 63) / 64;
     hipLaunchKernelGGL(aln_traceback_kernel, dim3(grid), dim3(64), 0, s, *a);
+    hipLaunchKernelGGL(aln_traceback_expand_kernel, dim3((a->n_pairs + 3) / 4), dim3(256), 0, s, *a);
 }
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s)
