@@ -36,9 +36,19 @@ __device__ __forceinline__ int v_add3_m1(int a, int b)         // a + b - 1
 }
 __device__ __forceinline__ int v_pack11(int t, int kterm)      // (t << 11) + kterm, kterm wave-uniform
 {
-    int d;
-    asm("v_lshl_add_u32 %0, %1, 11, %2" : "=v"(d) : "v"(t), "s"(kterm));
-    return d;
+    return (int)(((uint32_t)t << 11) + (uint32_t)kterm);      // the compiler emits v_lshl_add_u32
+}
+// The heart of a cell as ONE statement (hipcc pads every asm statement with a wait state, so one statement per cell,
+// not one per instruction):  key = max3(top + negp, left + negp - 1, c);  nt = (key & ~3) | 2
+__device__ __forceinline__ void v_cell(int top, int left, int negp, int c, int &key, int &nt)
+{
+    int a, b;
+    asm("v_add_u32 %0, %4, %6\n\t"
+        "v_add3_u32 %1, %5, %6, -1\n\t"
+        "v_max3_i32 %2, %0, %1, %7\n\t"
+        "v_and_or_b32 %3, %2, -4, 2"
+        : "=&v"(a), "=&v"(b), "=&v"(key), "=v"(nt)
+        : "v"(top), "v"(left), "v"(negp), "v"(c));
 }
 
 template <int R> struct ProfWord;
@@ -84,6 +94,8 @@ struct FastIn {
     bool hazard;
     int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair
     uint32_t last_flip;
+    uint16_t *qo_pad;         // single-pair kernel: LDS, q[x] * 64R at index x + 63, zeros elsewhere (N + 192 entries)
+    int *bring;               // single-pair kernel: LDS, 2 x 64 ints
     const uint64_t *gin;      // single-pair kernel: granule rows
     uint64_t *gout;
     uint32_t *abort_flag;
@@ -107,7 +119,7 @@ __device__ __forceinline__ bool better_i(int v, uint32_t y, uint32_t x, int bv, 
     return x > bx || (x == bx && y > by);                                 // last in column-major order (aligner_core.rs:224)
 }
 
-template <int SEM, int R, bool SINGLE, bool FIRST>
+template <int SEM, int R, bool SINGLE, bool FIRST, bool LAST>
 struct FastStrip {
     static constexpr int SPB = 16 / R;
     static constexpr uint32_t STRIP_ROWS = SINGLE ? 64u * R : (uint32_t)ALN_STRIP_ROWS;
@@ -115,7 +127,7 @@ struct FastStrip {
     using PW = typename ProfWord<R>::T;
     const FastIn in;
     const uint32_t strip;
-    const bool last;
+    static constexpr bool last = LAST;
     const int lane;
     const uint32_t N;
     uint32_t lb, rb, yb;
@@ -126,8 +138,13 @@ struct FastStrip {
     PW pw;
     const uint8_t *prow;       // this lane's column of the profile: prof + lane*R
 
-    __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s, bool l)
-        : in(i), strip(s), last(l), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
+    // single-pair kernel: query offsets and the incoming boundary row are staged in LDS
+    const uint8_t *qo_lane;    // &qo_pad[63 - lane] (u16 entries: q[x] * 64R, zero padded on both sides)
+    int *bring;                // 2 x 64 T values of the row above this strip
+    int qv, top0v;
+
+    __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s)
+        : in(i), strip(s), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
 
     // next 64 columns of the row above this strip (T form), one per lane
     __device__ __forceinline__ int load_boundary(uint32_t xi)
@@ -161,21 +178,28 @@ struct FastStrip {
     {
         if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
-            if (!FIRST) inchunk = load_boundary(xi);
+            if (!FIRST && !SINGLE) inchunk = load_boundary(xi);
             if (SEM == ALN_CORE_LOCAL && FIRST && in.hazard) advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
-            qchunk = (xi + 1 < N) ? (int)in.q[xi + 1] * (64 * R) : 0;
+            if (!SINGLE) qchunk = (xi + 1 < N) ? (int)in.q[xi + 1] * (64 * R) : 0;
         }
         const int sel = (int)(k & 63u);
         int top0;
         if (FIRST) top0 = LOCAL ? 2 : ((k + 1 == N) ? 2 + (int)(N + 1) * in.nd4 : 2 + (int)(k + 1) * in.nd4);
+        else if (SINGLE) top0 = top0v;                          // read from the LDS ring one step ago
         else top0 = __builtin_amdgcn_readlane(inchunk, sel);
         const int topIn = shr1_i(top0, bottom);                 // lane 0 <- row above the strip, lane l <- lane l-1
+        if (SINGLE && !FIRST) top0v = bring[(k + 1) & 127u];    // next step's boundary cell (broadcast read)
         // cross-lane reads stay in wave-uniform control flow: inside a divergent branch the compiler may compute
         // their operand for the active lanes only
         const uint32_t adv = (SEM == ALN_CORE_LOCAL && FIRST) ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, sel) : 0u;
         const PW pwc = pw;                                      // profile bytes of THIS step (loaded one step ago)
-        qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);   // next step's query code reaches every lane
-        pw = *reinterpret_cast<const PW *>(prow + qoff);
+        if constexpr (SINGLE) {
+            pw = *reinterpret_cast<const PW *>(prow + qv);                           // step k+1: column k+1-lane
+            qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 2));         // step k+2
+        } else {
+            qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);             // next step's query code reaches every lane
+            pw = *reinterpret_cast<const PW *>(prow + qoff);
+        }
         // end-cell tie-break term of this step: earlier steps win (core) / later steps win (legacy)
         const int kterm = (SEM == ALN_CORE_LOCAL) ? (int)(2047u - (k & 2047u)) : (int)(k & 2047u);
         const uint32_t xm1 = k - (uint32_t)lane;
@@ -192,12 +216,14 @@ struct FastStrip {
                 if (SEM == ALN_CORE_LOCAL) negp = zr ? in.nd4 : in.ne4;
                 else if (SEM == ALN_CORE_GLOBAL) negp = (r == 0 && FIRST && lane == 0 && k == 0) ? in.nd4 : in.ne4;
                 else negp = in.nd4;
-                const int a = top + negp;
-                const int b = v_add3_m1(Tl[r], negp);
                 const int c = diag + prof_byte<R>(pwc, r);
-                int key = v_max3(a, b, c);
-                if (SEM == ALN_LEGACY_LOCAL) key = max(key, 3);
-                const int nt = v_tform(key);
+                int key, nt;
+                if (SEM == ALN_LEGACY_LOCAL) {
+                    key = max(v_max3(top + negp, v_add3_m1(Tl[r], negp), c), 3);
+                    nt = v_tform(key);
+                } else {
+                    v_cell(top, Tl[r], negp, c, key, nt);
+                }
                 int stored = key;
                 if (SEM == ALN_CORE_LOCAL) { zr = (nt == 2); stored = zr ? 3 : key; }
                 dw = __builtin_amdgcn_alignbit((uint32_t)stored, dw, 2);
@@ -223,17 +249,24 @@ struct FastStrip {
                 in.zrow[xm1 + 1] = (hb == 2) ? 1 : 0;
             }
         }
-        if (SINGLE && !last) {
-            // bottom row to the strip below: lane 63's cell of column c = k - 63 enters a 64-deep lane shift register
-            // (DPP wave_shl:1); every 16 columns the newest 16 lanes publish their granules (one 128-B sc1 store)
-            outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);   // lane i <- lane i+1, lane 63 <- bottom
-            const uint32_t c = k - 63u;
-            if (k >= 63u && c < N && ((c & 15u) == 15u || c + 1 == N)) {
-                const uint32_t col = c - 63u + (uint32_t)lane;            // column held by this lane (wraps if < 0)
-                const uint32_t first_new = c & ~15u;
-                if (col >= first_new && col <= c) granule_store(in.gout + col, outq);
-            }
-        }
+        // bottom row to the strip below: lane 63's newest cell enters a 64-deep lane shift register (DPP wave_shl:1)
+        if (SINGLE && !LAST) outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);
+    }
+
+    // single-pair kernel: after step k lanes 48..63 hold the bottom-row cells of columns c-15..c, c = k - 63; one
+    // 128-byte write-through store publishes them to the strip below
+    __device__ __forceinline__ void publish(const uint32_t k)
+    {
+        const uint32_t c = k - 63u;
+        const uint32_t col = c - 63u + (uint32_t)lane;              // wraps for lanes that hold nothing yet
+        if (lane >= 48 && col < N) granule_store(in.gout + col, outq);
+    }
+
+    // single-pair kernel: stage the 64 boundary cells of columns 64m .. 64m+63 in the LDS ring (polls their granules)
+    __device__ __forceinline__ void stage_boundary(const uint32_t m)
+    {
+        const int v = load_boundary(64u * m + (uint32_t)lane);
+        bring[(m & 1u) * 64u + lane] = v;
     }
 
     // four blocks of SPB steps -> one 16-byte store per lane (1 KiB per wave, coalesced).  The block loop is a real
@@ -244,8 +277,11 @@ struct FastStrip {
         uint4 v = make_uint4(0, 0, 0, 0);
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t k0 = (kb + j) * SPB;
+            if (SINGLE && !FIRST && ((k0 + SPB) & 63u) == 0) stage_boundary((k0 + SPB) >> 6);   // one block ahead
 #pragma unroll
-            for (int kk = 0; kk < SPB; ++kk) step<MASKED>((kb + j) * SPB + kk);
+            for (int kk = 0; kk < SPB; ++kk) step<MASKED>(k0 + kk);
+            if (SINGLE && !LAST && k0 + SPB >= 64u && ((k0 + SPB) & 15u) == 0) publish(k0 + SPB - 1);
             if (j == 0) v.x = dw;
             else if (j == 1) v.y = dw;
             else if (j == 2) v.z = dw;
@@ -294,10 +330,10 @@ struct FastStrip {
         const uint32_t y0 = strip * STRIP_ROWS;
         const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
         const uint32_t L = (rows + R - 1) / R;
-        const uint32_t nsteps = (SINGLE && !last) ? N + 63 : N + L - 1;
+        const uint32_t nsteps = (SINGLE && !LAST) ? N + 63 : N + L - 1;
         yb = y0 + (uint32_t)lane * R;
         lb = (rows - 1) / R; rb = (rows - 1) % R;
-        zsel_on = (SEM == ALN_CORE_LOCAL) && last && in.hazard;
+        zsel_on = (SEM == ALN_CORE_LOCAL) && LAST && in.hazard;
         prow = in.prof + lane * R;
 
         // ---- query profile of this strip's rows: P[c][row] = 4*S[t[row]][c] - 2  (int8), row-contiguous per code
@@ -325,8 +361,16 @@ struct FastStrip {
         }
         hdiag = LOCAL || yb == 0 ? 2 : 2 + (int)yb * in.nd4;            // H[yb][0]; yb < M always for valid lanes
         bottom = Tl[R - 1];
-        inchunk = 2; qchunk = 0; advchunk = 0; dw = 0; outq = 0;
-        qoff = (lane == 0) ? (int)in.q[0] * (64 * R) : 0;
+        inchunk = 2; qchunk = 0; advchunk = 0; dw = 0; outq = 0; qv = 0; top0v = 2;
+        if constexpr (SINGLE) {
+            qo_lane = reinterpret_cast<const uint8_t *>(in.qo_pad + 63 - lane);
+            bring = in.bring;
+            if (!FIRST) { stage_boundary(0); top0v = bring[0]; }
+            qoff = *reinterpret_cast<const uint16_t *>(qo_lane);                      // step 0: column -lane
+            qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2);                    // step 1
+        } else {
+            qoff = (lane == 0) ? (int)in.q[0] * (64 * R) : 0;
+        }
         pw = *reinterpret_cast<const PW *>(prow + qoff);
 
         // directions: four blocks per lane per 16-byte store (aln_device.h); all segment ends are whole quads
@@ -362,6 +406,7 @@ struct FastStrip {
             }
             if (LOCAL && kb * SPB == chunk_base + 2048u) { fold(o, chunk_base); chunk_base += 2048u; }
         }
+        if (SINGLE && !LAST) publish(nkb * SPB - 1);     // the last (up to 15) columns
         o.brow_bad = o.brow_bad || brow_bad;
         o.aborted = o.aborted || aborted;
         if (ckmode && in.ck_mode == 2) return o;         // ran out of checkpoints: the caller escalates to a full pass
@@ -376,20 +421,26 @@ struct FastStrip {
     }
 };
 
-template <int SEM, bool SINGLE>
+// Batch kernels: every strip but the last has 512 rows (R = 8); the last one picks R by its row count.
+template <int SEM>
 __device__ __forceinline__ FastOut fast_strip(const FastIn &in, FastOut o, uint32_t s, bool last, int R)
 {
-    if (s == 0) {
-        if (R == 8) { FastStrip<SEM, 8, SINGLE, true> f(in, s, last); return f.run(o); }
-        if (R == 4) { FastStrip<SEM, 4, SINGLE, true> f(in, s, last); return f.run(o); }
-        if (R == 2) { FastStrip<SEM, 2, SINGLE, true> f(in, s, last); return f.run(o); }
-        FastStrip<SEM, 1, SINGLE, true> f(in, s, last);
+    if (!last) {
+        if (s == 0) { FastStrip<SEM, 8, false, true, false> f(in, s); return f.run(o); }
+        FastStrip<SEM, 8, false, false, false> f(in, s);
         return f.run(o);
     }
-    if (R == 8) { FastStrip<SEM, 8, SINGLE, false> f(in, s, last); return f.run(o); }
-    if (R == 4) { FastStrip<SEM, 4, SINGLE, false> f(in, s, last); return f.run(o); }
-    if (R == 2) { FastStrip<SEM, 2, SINGLE, false> f(in, s, last); return f.run(o); }
-    FastStrip<SEM, 1, SINGLE, false> f(in, s, last);
+    if (s == 0) {
+        if (R == 8) { FastStrip<SEM, 8, false, true, true> f(in, s); return f.run(o); }
+        if (R == 4) { FastStrip<SEM, 4, false, true, true> f(in, s); return f.run(o); }
+        if (R == 2) { FastStrip<SEM, 2, false, true, true> f(in, s); return f.run(o); }
+        FastStrip<SEM, 1, false, true, true> f(in, s);
+        return f.run(o);
+    }
+    if (R == 8) { FastStrip<SEM, 8, false, false, true> f(in, s); return f.run(o); }
+    if (R == 4) { FastStrip<SEM, 4, false, false, true> f(in, s); return f.run(o); }
+    if (R == 2) { FastStrip<SEM, 2, false, false, true> f(in, s); return f.run(o); }
+    FastStrip<SEM, 1, false, false, true> f(in, s);
     return f.run(o);
 }
 

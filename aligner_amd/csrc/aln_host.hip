@@ -254,6 +254,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
             if (R != 1 && R != 2 && R != 4 && R != 8) R = 2;
             while ((d.M + 64 * R - 1) / (64 * R) > 4096 && R < 8) R *= 2;      // keep every strip's wave resident
             if ((d.M + 64 * R - 1) / (64 * R) > 4096) single = false;
+            if ((uint64_t)rows * cols * 4 + (uint64_t)cols * 64 * R + 2ull * (d.N + 192) + 1024 > 65536) single = false;   // LDS budget
             if (single) {
                 const uint32_t ns = (d.M + 64 * R - 1) / (64 * R), spb = 16 / R;
                 dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * aln_uniform_strip_bytes(d.N, R));
@@ -403,7 +404,8 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         sa.ns = (d.M + 64 * sa.R - 1) / (64 * sa.R);
         sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
         sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
-        const uint32_t lds = (uint32_t)(((uint64_t)sa.rows * sa.cols * 4 + 15) & ~15ull) + sa.cols * 64u * sa.R;
+        const uint32_t lds = (uint32_t)(((uint64_t)sa.rows * sa.cols * 4 + 15) & ~15ull) + ((sa.cols * 64u * sa.R + 15u) & ~15u) +
+                             (((d.N + 192u) * 2u + 15u) & ~15u) + 512u;
         aln_launch_single_init(&sa, d.N + 66, s);
         for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
             sa.pass = pass;

@@ -444,7 +444,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
         for (uint32_t s = 0; s < ns; ++s) {
             const bool last = (s + 1 == ns);
             if (s > 0) __threadfence_block();            // strip s reads the boundary row strip s-1 stored
-            o = fast_strip<SEM, false>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8);
+            o = fast_strip<SEM>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8);
         }
         ++passes;
         __threadfence_block();
@@ -460,7 +460,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
                 in.ck_mode = 2; in.last_flip = last_flip;
                 FastOut ro = o;
                 ro.repaired = false; ro.brow_bad = false;
-                ro = fast_strip<SEM, false>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : 8);
+                ro = fast_strip<SEM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : 8);
                 __threadfence_block();
                 if (!__any(ro.repaired) || __any(ro.brow_bad)) break;     // escalate to a full pass
                 if (ns > 1) { converged = true; break; }                  // the bottom strip, hence z, is untouched
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
     in.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u) + (threadIdx.x >> 6) * a.prof_stride;
     in.nd4 = -4 * (int)a.del;
     in.ne4 = -4 * (int)a.ext;
-    in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr;
+    in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr; in.qo_pad = nullptr; in.bring = nullptr;
     in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.ck_mode = 0; in.last_flip = 0;
     uint32_t pair;
     while (next_pair(a, in.lane, pair)) {
@@ -611,8 +611,21 @@ __global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
     in.abort_flag = a.ctrl;
     FastOut o;
     o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
-    if (strip == 0) { FastStrip<SEM, R, true, true> fs(in, strip, last); o = fs.run(o); }
-    else { FastStrip<SEM, R, true, false> fs(in, strip, last); o = fs.run(o); }
+    // LDS: query offsets (q[x] * 64R at index x + 63, zero padded) and the boundary ring
+    const uint32_t prof_bytes = (a.cols * 64u * R + 15u) & ~15u;
+    in.qo_pad = reinterpret_cast<uint16_t *>(in.prof + prof_bytes);
+    in.bring = reinterpret_cast<int *>(in.prof + prof_bytes + (((desc.N + 192u) * 2u + 15u) & ~15u));
+    for (uint32_t i = threadIdx.x; i < desc.N + 192u; i += 64) {
+        const uint32_t x = i - 63u;
+        in.qo_pad[i] = (i >= 63u && x < desc.N) ? (uint16_t)((uint32_t)in.q[x] * 64u * R) : (uint16_t)0;
+    }
+    if (strip == 0) {
+        if (last) { FastStrip<SEM, R, true, true, true> fs(in, strip); o = fs.run(o); }
+        else { FastStrip<SEM, R, true, true, false> fs(in, strip); o = fs.run(o); }
+    } else {
+        if (last) { FastStrip<SEM, R, true, false, true> fs(in, strip); o = fs.run(o); }
+        else { FastStrip<SEM, R, true, false, false> fs(in, strip); o = fs.run(o); }
+    }
     if (is_local<SEM>()) reduce_best<SEM>(o);
     if (in.lane == 0) {
         int32_t *c = a.cand + 4 * strip;
