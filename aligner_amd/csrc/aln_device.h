@@ -96,6 +96,21 @@ struct TraceArgs {
     uint8_t blank;
 };
 
+// Parallel traceback of one large pair (uniform-R layout): per strip and entry column an "exit map", then a short
+// serial chain through the maps, then one walker per strip that writes its segment of the tag string.
+struct TraceSingleArgs {
+    const uint8_t *seqs;
+    const PairDesc *descs;
+    uint32_t pair;
+    const uint8_t *dirs;
+    aln_pair_result *results;
+    uint8_t *tb;
+    int32_t semantics;
+    uint32_t R, ns;
+    uint4 *map;               // ns x (N + 1) entries {exit cx, exit cy, steps, stopped}
+    uint4 *seg;               // per strip {entry cy, entry cx, tag-string offset, valid}
+};
+
 // stored tag -> Direction discriminant (enums.rs:9-15: Top=0 Left=1 Diagonal=2 Beginning=3)
 __host__ __device__ inline int aln_tag_to_dir(int t) { return t == 3 ? 3 : 2 - t; }
 __host__ __device__ inline int aln_dir_to_tag(int d) { return d == 3 ? 3 : 2 - d; }

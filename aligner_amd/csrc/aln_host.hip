@@ -23,6 +23,8 @@
 
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
+extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
+extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s);
 extern "C" void aln_launch_single(const SingleArgs *a, uint32_t lds_bytes, int with_serial, hipStream_t s);
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
@@ -76,6 +78,8 @@ struct aln_batch {
     int32_t *d_cand = nullptr;
     uint32_t *d_ctrl = nullptr;
     uint32_t single_max_n = 0;
+    uint4 *d_tbmap = nullptr;   // parallel traceback of large pairs: exit maps + per-strip segments
+    uint64_t tbmap_entries = 0;
     hipStream_t last_stream = nullptr;
     // timing ring: one event triple per run (fill start, fill end, traceback end), recorded on the launch stream
     bool timing = false;
@@ -157,7 +161,7 @@ static void batch_free(aln_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     void *ptrs[] = {b->d_seqs, b->d_descs, b->d_order, b->d_counter, b->d_dirs, b->d_results, b->d_tb, b->d_scratch,
-                    b->d_matrix, b->d_hmat, b->d_granules, b->d_advice1, b->d_cand, b->d_ctrl};
+                    b->d_matrix, b->d_hmat, b->d_granules, b->d_advice1, b->d_cand, b->d_ctrl, b->d_tbmap};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -264,6 +268,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
                 const uint64_t gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
                 b->granule_bytes = std::max<uint64_t>(b->granule_bytes, std::max<uint64_t>((uint64_t)ns * gstride * 8, 4ull * (d.M + 2)));
                 b->single_max_n = std::max(b->single_max_n, std::max(d.N, ns));
+                b->tbmap_entries = std::max<uint64_t>(b->tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
             }
         }
         d.dir_off = dir_total;
@@ -325,6 +330,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
         BCHK(dmalloc((void **)&b->d_advice1, 2ull * (b->single_max_n + 128)));
         BCHK(dmalloc((void **)&b->d_cand, 16ull * (b->single_max_n + 64)));
         BCHK(dmalloc((void **)&b->d_ctrl, 256));
+        BCHK(dmalloc((void **)&b->d_tbmap, b->tbmap_entries * 16));
     }
     if (n) {
         BCHK(hipMemcpy(b->d_seqs, seqs, seq_bytes, hipMemcpyHostToDevice));
@@ -421,7 +427,17 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         TraceArgs ta{};
         ta.seqs = b->d_seqs; ta.descs = b->d_descs; ta.n_pairs = (uint32_t)b->n; ta.dirs = b->d_dirs;
         ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code;
-        aln_launch_traceback(&ta, s);
+        aln_launch_traceback(&ta, s);       // every pair except those in the uniform-R layout (handled below)
+        for (size_t j = 0; j < b->single_pairs.size(); ++j) {
+            const PairDesc &d = b->descs[b->single_pairs[j]];
+            TraceSingleArgs tsa{};
+            tsa.seqs = b->d_seqs; tsa.descs = b->d_descs; tsa.pair = b->single_pairs[j]; tsa.dirs = b->d_dirs;
+            tsa.results = b->d_results; tsa.tb = b->d_tb; tsa.semantics = b->params.semantics;
+            tsa.R = b->single_r[j]; tsa.ns = (d.M + 64 * tsa.R - 1) / (64 * tsa.R);
+            tsa.map = b->d_tbmap; tsa.seg = b->d_tbmap + (uint64_t)tsa.ns * (d.N + 1);
+            aln_launch_traceback_single(&tsa, d.N, s);
+        }
+        aln_launch_traceback_expand(&ta, s);
         HIPCHK(hipGetLastError());
     }
     if (ev) { HIPCHK(hipEventRecord(ev[2], s)); b->ev_runs++; }

@@ -823,6 +823,7 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     const PairDesc &d = a.descs[pair];
     aln_pair_result &res = a.results[pair];
     if (res.status != ALN_OK) return;
+    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) return;      // large pairs: aln_tb_single_* kernels
     const uint8_t *__restrict__ q = a.seqs + d.q_off;
     const uint8_t *__restrict__ t = a.seqs + d.t_off;
     const uint32_t cap = d.N + d.M + 2;
@@ -864,6 +865,113 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     }
     res.start_y = cy; res.start_x = cx;
     res.aln_len = len + 1;                              // + the duplicated seed pair, written by the expand kernel
+}
+
+// ---------------------------------------------------------------- parallel traceback of one large pair
+// Walks from (cy, cx) while the walk stays inside the strip whose rows are y0+1 .. (uniform-R layout), following the
+// same rules as aln_traceback_kernel.  Returns true if the walk ended (Beginning / origin), false if it left the strip
+// upwards (then cy == y0).  `ops` (optional) receives the tags.
+__device__ __forceinline__ bool walk_in_strip(const uint32_t *wbase, uint32_t y0, uint32_t lgR, uint32_t N, bool global,
+                                              uint32_t &cy, uint32_t &cx, uint32_t &steps, uint8_t *ops)
+{
+    const uint32_t R = 1u << lgR, sh = 4u - lgR;
+    for (;;) {
+        if (cy == 0 || cx == 0) {
+            if (!global || (cy == 0 && cx == 0)) return true;            // Beginning (simple/mod.rs:55-57)
+            if (cy == 0) { if (ops) ops[steps] = 1; ++steps; --cx; continue; }      // D[0][x] = Left
+            if (ops) ops[steps] = 2;                                      // D[y][0] = Top
+            ++steps; --cy;
+            if (cy <= y0) return cy == 0 && false;
+            continue;
+        }
+        if (cy <= y0) return false;
+        const uint32_t i = cy - 1 - y0;
+        const uint32_t lane = i >> lgR, r = i & (R - 1u);
+        const uint32_t k = cx - 1 + lane, kb = k >> sh;
+        const uint32_t word = wbase[(((uint64_t)(kb >> 2) * 64u + lane) << 2) + (kb & 3u)];
+        const uint32_t bend = (kb << sh) + (1u << sh) - 1u, lend = lane + N - 1u;
+        const uint32_t e = min(bend, lend);
+        const uint32_t tag = (word >> (30u - 2u * (((e - k) << lgR) + (R - 1u - r)))) & 3u;
+        if (tag == 3u) return true;
+        if (ops) ops[steps] = (uint8_t)tag;
+        ++steps;
+        cy -= (tag != 1u); cx -= (tag != 2u);
+    }
+}
+
+// exit map: thread (x, s) enters strip s on its bottom row at column x
+extern "C" __global__ __launch_bounds__(256) void aln_tb_single_maps_kernel(TraceSingleArgs a)
+{
+    const PairDesc &d = a.descs[a.pair];
+    if (a.results[a.pair].status != ALN_OK || (d.layout & 0xffu) != ALN_LAYOUT_UNIFORM) return;   // serial fallback: aln_traceback_kernel
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (x > d.N) return;
+    const uint32_t lgR = 31u - (uint32_t)__builtin_clz(a.R), rows = 64u << lgR;
+    const uint32_t y0 = s * rows;
+    const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
+    const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
+    uint32_t cy = min(d.M, y0 + rows), cx = x, steps = 0;
+    const bool stopped = walk_in_strip(wbase, y0, lgR, d.N, global, cy, cx, steps, nullptr);
+    a.map[(size_t)s * (d.N + 1) + x] = make_uint4(cx, cy, steps, stopped ? 1u : 0u);
+}
+
+// one thread: from the end cell through its own strip, then strip by strip through the maps
+extern "C" __global__ void aln_tb_single_chain_kernel(TraceSingleArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const PairDesc &d = a.descs[a.pair];
+    aln_pair_result &res = a.results[a.pair];
+    for (uint32_t s = 0; s < a.ns; ++s) a.seg[s] = make_uint4(0, 0, 0, 0);
+    if (res.status != ALN_OK || (d.layout & 0xffu) != ALN_LAYOUT_UNIFORM) return;
+    const uint32_t lgR = 31u - (uint32_t)__builtin_clz(a.R), rows = 64u << lgR;
+    const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
+    const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
+    uint32_t cy = res.end_y, cx = res.end_x;
+    if (legacy) { cy -= 1; cx -= 1; }
+    uint32_t off = 0;
+    bool stopped = (cy == 0 || cx == 0) && (!global || (cy == 0 && cx == 0));
+    if (!stopped && cy == 0) {                       // only the top border is left (global)
+        a.seg[0] = make_uint4(cy, cx, 0, 1);
+        off = cx; cx = 0; stopped = true;
+    }
+    if (!stopped) {
+        uint32_t s = (cy - 1) >> (6 + lgR);
+        // first segment: from the end cell, which need not be on the strip's bottom row
+        a.seg[s] = make_uint4(cy, cx, 0, 1);
+        const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
+        uint32_t steps = 0;
+        stopped = walk_in_strip(wbase, s * rows, lgR, d.N, global, cy, cx, steps, nullptr);
+        off = steps;
+        while (!stopped && s > 0) {
+            --s;
+            a.seg[s] = make_uint4(cy, cx, off, 1);
+            const uint4 m = a.map[(size_t)s * (d.N + 1) + cx];
+            cx = m.x; cy = m.y; off += m.z; stopped = m.w != 0;
+        }
+        if (!stopped && global && cy == 0 && cx != 0) {      // left strip 0 through the top border: D[0][x] = Left
+            // (walk_in_strip handles the borders inside strip 0, so this cannot happen; kept as a guard)
+            off += cx; cx = 0;
+        }
+    }
+    res.start_y = cy; res.start_x = cx;
+    res.aln_len = off + 1;
+}
+
+// one thread per strip: re-walks its segment and writes the tags at their final offset
+extern "C" __global__ __launch_bounds__(64) void aln_tb_single_segments_kernel(TraceSingleArgs a)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.ns) return;
+    const PairDesc &d = a.descs[a.pair];
+    if (a.results[a.pair].status != ALN_OK || (d.layout & 0xffu) != ALN_LAYOUT_UNIFORM) return;
+    const uint4 sg = a.seg[s];
+    if (sg.w == 0) return;
+    const uint32_t lgR = 31u - (uint32_t)__builtin_clz(a.R), rows = 64u << lgR;
+    const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
+    uint8_t *ops = a.tb + d.tb_off + 2ull * (d.N + d.M + 2) + sg.z;
+    const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
+    uint32_t cy = sg.x, cx = sg.y, steps = 0;
+    walk_in_strip(wbase, s * rows, lgR, d.N, global, cy, cx, steps, ops);
 }
 
 // Pass 2, one wave per pair: turns the tag string into the two aligned code strings in final (forward) order.
@@ -980,7 +1088,16 @@ extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
 {
     const uint32_t grid = (a->n_pairs + 63) / 64;
     hipLaunchKernelGGL(aln_traceback_kernel, dim3(grid), dim3(64), 0, s, *a);
+}
+extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s)
+{
     hipLaunchKernelGGL(aln_traceback_expand_kernel, dim3((a->n_pairs + 3) / 4), dim3(256), 0, s, *a);
+}
+extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s)
+{
+    hipLaunchKernelGGL(aln_tb_single_maps_kernel, dim3((N + 1 + 255) / 256, a->ns), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(aln_tb_single_chain_kernel, dim3(1), dim3(64), 0, s, *a);
+    hipLaunchKernelGGL(aln_tb_single_segments_kernel, dim3((a->ns + 63) / 64), dim3(64), 0, s, *a);
 }
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s)
