@@ -142,6 +142,7 @@ struct FastStrip {
     const uint8_t *qo_lane;    // &qo_pad[63 - lane] (u16 entries: q[x] * 64R, zero padded on both sides)
     int *bring;                // 2 x 64 T values of the row above this strip
     int qv, top0v;
+    uint64_t gpre;             // prefetched granule of the next 16-column group (lanes 0..15)
 
     __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s)
         : in(i), strip(s), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
@@ -262,11 +263,30 @@ struct FastStrip {
         if (lane >= 48 && col < N) granule_store(in.gout + col, outq);
     }
 
-    // single-pair kernel: stage the 64 boundary cells of columns 64m .. 64m+63 in the LDS ring (polls their granules)
-    __device__ __forceinline__ void stage_boundary(const uint32_t m)
+    // single-pair kernel: boundary cells arrive 16 columns at a time.  The granules of group j+1 are requested when
+    // group j is staged (lanes 0..15, non-blocking), so in steady state staging never waits on HBM/L2; only a consumer
+    // that has caught up with its producer spins (bounded) until the tags appear.
+    __device__ __forceinline__ void stage_boundary16(const uint32_t j)
     {
-        const int v = load_boundary(64u * m + (uint32_t)lane);
-        bring[(m & 1u) * 64u + lane] = v;
+        const uint32_t col = 16u * j + (uint32_t)lane;
+        const bool need = lane < 16 && col < N;
+        uint64_t g = gpre;
+        uint32_t spins = 0;
+        while (!__all(!need || (g >> 32) != 0)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (need) g = granule_load(in.gin + col);
+            ++spins;
+            if (spins > (1u << 22) ||
+                ((spins & 1023u) == 0 && __hip_atomic_load(in.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                // the producer never arrived: poison the run instead of hanging the GPU
+                if (lane == 0) __hip_atomic_store(in.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                aborted = true;
+                break;
+            }
+        }
+        if (lane < 16) bring[col & 127u] = need ? (int)(uint32_t)g : 2;
+        const uint32_t ncol = col + 16u;
+        gpre = (lane < 16 && ncol < N) ? granule_load(in.gin + ncol) : 0ull;       // group j+1, consumed next time
     }
 
     // four blocks of SPB steps -> one 16-byte store per lane (1 KiB per wave, coalesced).  The block loop is a real
@@ -278,7 +298,7 @@ struct FastStrip {
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; ++j) {
             const uint32_t k0 = (kb + j) * SPB;
-            if (SINGLE && !FIRST && ((k0 + SPB) & 63u) == 0) stage_boundary((k0 + SPB) >> 6);   // one block ahead
+            if (SINGLE && !FIRST && ((k0 + SPB) & 15u) == 0) stage_boundary16((k0 + SPB) >> 4);   // one block ahead
 #pragma unroll
             for (int kk = 0; kk < SPB; ++kk) step<MASKED>(k0 + kk);
             if (SINGLE && !LAST && k0 + SPB >= 64u && ((k0 + SPB) & 15u) == 0) publish(k0 + SPB - 1);
@@ -365,7 +385,8 @@ struct FastStrip {
         if constexpr (SINGLE) {
             qo_lane = reinterpret_cast<const uint8_t *>(in.qo_pad + 63 - lane);
             bring = in.bring;
-            if (!FIRST) { stage_boundary(0); top0v = bring[0]; }
+            gpre = (!FIRST && lane < 16 && (uint32_t)lane < N) ? granule_load(in.gin + lane) : 0ull;
+            if (!FIRST) { stage_boundary16(0); top0v = bring[0]; }
             qoff = *reinterpret_cast<const uint16_t *>(qo_lane);                      // step 0: column -lane
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2);                    // step 1
         } else {
