@@ -26,7 +26,10 @@
 
 #include "../../include/aligner_hip.h"
 
-#define ALN_STRIP_ROWS 512      // rows per full strip (64 lanes x R=8)
+#ifndef ALN_FULL_R
+#define ALN_FULL_R 8             // rows per lane in a full strip of the batch kernels
+#endif
+#define ALN_STRIP_ROWS (64 * ALN_FULL_R)   // rows per full strip
 #define ALN_LAYOUT_SKEW 0u      // 512-row strips, R = 8 except the last strip (batch kernels)
 #define ALN_LAYOUT_ROWMAJOR 1u  // serial-order fallback
 #define ALN_LAYOUT_UNIFORM 2u   // every strip has 64*R rows, R in bits 8..15 (single-pair kernel)
@@ -125,7 +128,8 @@ __host__ __device__ inline uint32_t aln_dir_bitpos(uint32_t k, uint32_t r, uint3
 // rows handled per lane in the strip that starts `rem` rows before the end of the target
 __host__ __device__ inline int aln_pick_r(uint32_t rem)
 {
-    return rem > 256 ? 8 : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+    const int r = rem > 256 ? 8 : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+    return r > ALN_FULL_R ? ALN_FULL_R : r;
 }
 __host__ __device__ inline uint32_t aln_num_strips(uint32_t M) { return (M + ALN_STRIP_ROWS - 1) / ALN_STRIP_ROWS; }
 // blocks (of SPB steps) a strip of `nsteps` steps stores, padded to whole quads
@@ -137,7 +141,7 @@ __host__ __device__ inline uint64_t aln_dir_word_index(uint32_t k, uint32_t lane
     return ((uint64_t)(kb >> 2) * 64u + lane) * 4u + (kb & 3u);
 }
 // bytes of one full (R = 8) strip region: steps N+63, 2 steps per block, 256 B per block
-__host__ __device__ inline uint64_t aln_strip_bytes(uint32_t N) { return (uint64_t)aln_strip_blocks(N + 63, 2) * 256u; }
+__host__ __device__ inline uint64_t aln_strip_bytes(uint32_t N) { return (uint64_t)aln_strip_blocks(N + 63, 16 / ALN_FULL_R) * 256u; }
 // bytes of one strip of the uniform-R layout (single-pair kernel)
 __host__ __device__ inline uint64_t aln_uniform_strip_bytes(uint32_t N, uint32_t R) { return (uint64_t)aln_strip_blocks(N + 63, 16u / R) * 256u; }
 __host__ __device__ inline uint64_t aln_rowmajor_bytes(uint32_t N, uint32_t M)

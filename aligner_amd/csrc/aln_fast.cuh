@@ -39,17 +39,26 @@ __device__ __forceinline__ int v_pack11(int t, int kterm)      // (t << 11) + kt
     return (int)(((uint32_t)t << 11) + (uint32_t)kterm);      // the compiler emits v_lshl_add_u32
 }
 // The heart of a cell as ONE statement (hipcc pads every asm statement with a wait state, so one statement per cell,
-// not one per instruction):  key = max3(top + negp, left + negp - 1, c);  nt = (key & ~3) | 2
-__device__ __forceinline__ void v_cell(int top, int left, int negp, int c, int &key, int &nt)
+// not one per instruction).  pw holds four int8 profile scores; B selects this row's byte:
+//   c = diag + sext(pw.byte[B]);  key = max3(top + negp, left + negp - 1, c);  nt = (key & ~3) | 2
+#define ALN_CELL_ASM(BYTE)                                                                                    \
+    asm("v_add_u32_sdwa %0, %8, sext(%9) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t" \
+        "v_add_u32 %1, %5, %7\n\t"                                                                            \
+        "v_add3_u32 %2, %6, %7, -1\n\t"                                                                       \
+        "v_max3_i32 %3, %1, %2, %0\n\t"                                                                       \
+        "v_and_or_b32 %4, %3, -4, 2"                                                                          \
+        : "=&v"(c), "=&v"(a), "=&v"(b), "=&v"(key), "=v"(nt)                                                  \
+        : "v"(top), "v"(left), "v"(negp), "v"(diag), "v"(pw))
+template <int B>
+__device__ __forceinline__ void v_cell(int top, int left, int negp, int diag, uint32_t pw, int &key, int &nt)
 {
-    int a, b;
-    asm("v_add_u32 %0, %4, %6\n\t"
-        "v_add3_u32 %1, %5, %6, -1\n\t"
-        "v_max3_i32 %2, %0, %1, %7\n\t"
-        "v_and_or_b32 %3, %2, -4, 2"
-        : "=&v"(a), "=&v"(b), "=&v"(key), "=v"(nt)
-        : "v"(top), "v"(left), "v"(negp), "v"(c));
+    int a, b, c;
+    if constexpr (B == 0) ALN_CELL_ASM("BYTE_0");
+    else if constexpr (B == 1) ALN_CELL_ASM("BYTE_1");
+    else if constexpr (B == 2) ALN_CELL_ASM("BYTE_2");
+    else ALN_CELL_ASM("BYTE_3");
 }
+#undef ALN_CELL_ASM
 
 template <int R> struct ProfWord;
 template <> struct ProfWord<8> { using T = uint2; };
@@ -57,6 +66,13 @@ template <> struct ProfWord<4> { using T = uint32_t; };
 template <> struct ProfWord<2> { using T = uint16_t; };
 template <> struct ProfWord<1> { using T = uint8_t; };
 
+// the 32-bit word of the profile read that holds row r's byte
+template <int R>
+__device__ __forceinline__ uint32_t prof_word(const typename ProfWord<R>::T &pw, int r)
+{
+    if constexpr (R == 8) return r < 4 ? pw.x : pw.y;
+    else return (uint32_t)pw;
+}
 template <int R>
 __device__ __forceinline__ int prof_byte(const typename ProfWord<R>::T &pw, int r)
 {
@@ -217,17 +233,28 @@ struct FastStrip {
                 if (SEM == ALN_CORE_LOCAL) negp = zr ? in.nd4 : in.ne4;
                 else if (SEM == ALN_CORE_GLOBAL) negp = (r == 0 && FIRST && lane == 0 && k == 0) ? in.nd4 : in.ne4;
                 else negp = in.nd4;
-                const int c = diag + prof_byte<R>(pwc, r);
                 int key, nt;
                 if (SEM == ALN_LEGACY_LOCAL) {
+                    const int c = diag + prof_byte<R>(pwc, r);
                     key = max(v_max3(top + negp, v_add3_m1(Tl[r], negp), c), 3);
                     nt = v_tform(key);
                 } else {
-                    v_cell(top, Tl[r], negp, c, key, nt);
+                    const uint32_t w32 = prof_word<R>(pwc, r);
+                    switch (r & 3) {                       // constant after unrolling: picks the SDWA byte select
+                    case 0: v_cell<0>(top, Tl[r], negp, diag, w32, key, nt); break;
+                    case 1: v_cell<1>(top, Tl[r], negp, diag, w32, key, nt); break;
+                    case 2: v_cell<2>(top, Tl[r], negp, diag, w32, key, nt); break;
+                    default: v_cell<3>(top, Tl[r], negp, diag, w32, key, nt); break;
+                    }
                 }
-                int stored = key;
-                if (SEM == ALN_CORE_LOCAL) { zr = (nt == 2); stored = zr ? 3 : key; }
-                dw = __builtin_amdgcn_alignbit((uint32_t)stored, dw, 2);
+                uint32_t stored = (uint32_t)key;
+                if (SEM == ALN_CORE_LOCAL) {
+                    zr = (nt == 2);
+                    // Beginning (H == 0) is tag 3: H == 0 <=> key in {0,1,2} <=> (unsigned)key < 4, so one unsigned max
+                    // sets the tag without a mask (negative keys are huge as unsigned and pass through)
+                    stored = max((uint32_t)key, 3u);
+                }
+                dw = __builtin_amdgcn_alignbit(stored, dw, 2);
                 if (LOCAL) rbv[r] = max(rbv[r], v_pack11(nt, kterm));
                 diag = Tl[r];
                 Tl[r] = nt;
@@ -447,8 +474,8 @@ template <int SEM>
 __device__ __forceinline__ FastOut fast_strip(const FastIn &in, FastOut o, uint32_t s, bool last, int R)
 {
     if (!last) {
-        if (s == 0) { FastStrip<SEM, 8, false, true, false> f(in, s); return f.run(o); }
-        FastStrip<SEM, 8, false, false, false> f(in, s);
+        if (s == 0) { FastStrip<SEM, ALN_FULL_R, false, true, false> f(in, s); return f.run(o); }
+        FastStrip<SEM, ALN_FULL_R, false, false, false> f(in, s);
         return f.run(o);
     }
     if (s == 0) {

@@ -304,7 +304,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     const uint64_t ck_bytes = b->fast ? (4ull * 18 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
     b->scratch_stride = brow_bytes + 2 * adv_bytes + ck_bytes;
     b->lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
-    if (b->fast) { b->prof_stride = cols * 512u; b->lds_bytes += 4u * b->prof_stride; }
+    if (b->fast) { b->prof_stride = cols * 64u * ALN_FULL_R; b->lds_bytes += 4u * b->prof_stride; }
 
     // ---- device allocations + H2D
     uint64_t seq_bytes = 0;
@@ -507,7 +507,7 @@ extern "C" uint64_t aln_batch_direction_bytes(const aln_batch *b)
         for (uint32_t s = 0; s < ns; ++s) {
             const bool last = s + 1 == ns;
             const uint32_t rem = d.M - s * ALN_STRIP_ROWS;
-            const int R = last ? aln_pick_r(rem) : 8;
+            const int R = last ? aln_pick_r(rem) : ALN_FULL_R;
             const uint32_t rows = std::min<uint32_t>(rem, 64u * R), L = (rows + R - 1) / R, spb = 16 / R;
             total += (uint64_t)aln_strip_blocks(d.N + L - 1, spb) * 256u;
         }

@@ -374,7 +374,7 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
             for (uint32_t s = 0; s < ns; ++s) {
                 const bool last = (s + 1 == ns);
                 if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
-                const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8;
+                const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R;
                 if (R == 8) run_strip<SC, SEM, 8>(w, s, last);
                 else if (R == 4) run_strip<SC, SEM, 4>(w, s, last);
                 else if (R == 2) run_strip<SC, SEM, 2>(w, s, last);
@@ -444,7 +444,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
         for (uint32_t s = 0; s < ns; ++s) {
             const bool last = (s + 1 == ns);
             if (s > 0) __threadfence_block();            // strip s reads the boundary row strip s-1 stored
-            o = fast_strip<SEM>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : 8);
+            o = fast_strip<SEM>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R);
         }
         ++passes;
         __threadfence_block();
@@ -460,7 +460,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
                 in.ck_mode = 2; in.last_flip = last_flip;
                 FastOut ro = o;
                 ro.repaired = false; ro.brow_bad = false;
-                ro = fast_strip<SEM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : 8);
+                ro = fast_strip<SEM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : ALN_FULL_R);
                 __threadfence_block();
                 if (!__any(ro.repaired) || __any(ro.brow_bad)) break;     // escalate to a full pass
                 if (ns > 1) { converged = true; break; }                  // the bottom strip, hence z, is untouched
@@ -729,7 +729,7 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
     } else {
         strip = (y - 1) / ALN_STRIP_ROWS;
         const uint32_t ns = aln_num_strips(d.M);
-        R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8;
+        R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : ALN_FULL_R;
         i = (y - 1) - strip * ALN_STRIP_ROWS;
         strip_bytes = aln_strip_bytes(d.N);
     }
@@ -760,7 +760,7 @@ __device__ __forceinline__ uint32_t dir_prefetch(const uint8_t *dirs, const Pair
     } else {
         strip = (y - 1) / ALN_STRIP_ROWS;
         const uint32_t ns = aln_num_strips(d.M);
-        R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8;
+        R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : ALN_FULL_R;
         i = (y - 1) - strip * ALN_STRIP_ROWS;
         strip_bytes = aln_strip_bytes(d.N);
     }
@@ -804,7 +804,7 @@ __device__ __forceinline__ StripView strip_view(const uint8_t *dirs, const PairD
     } else {
         const uint32_t strip = (y - 1) / ALN_STRIP_ROWS;
         const uint32_t ns = aln_num_strips(d.M);
-        const uint32_t R = (strip + 1 == ns) ? (uint32_t)aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : 8u;
+        const uint32_t R = (strip + 1 == ns) ? (uint32_t)aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : (uint32_t)ALN_FULL_R;
         v.lgR = 31u - (uint32_t)__builtin_clz(R);
         v.y0 = strip * ALN_STRIP_ROWS;
         v.wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_strip_bytes(d.N));

@@ -242,3 +242,62 @@ def test_c4_10k_pair_matches_oracle(orc, blosum62):
     """10k x 10k protein, core local 11/2, homolog variant (long real alignment): score, coords, strings."""
     q, t = workloads.c4_pair(homolog=True)
     check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=False)
+
+
+def test_c5_sample_matches_oracle(orc, blosum62):
+    """BASELINE C5 at its real lengths (200..2000 aa) on a 1500-pair sample: every summary and both aligned strings.
+    Exercises multi-strip pairs, the checkpointed first pass and the localized row-1 repair."""
+    b = workloads.c5_batch(n_pairs=1500)
+    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    passes = got.results["passes"]
+    assert ((passes & 0x80) == 0).all()              # nobody needed the strict-order routine
+    assert ((passes & 0xff) == 1).mean() > 0.9       # the first full pass (+ at most a localized repair) suffices
+
+
+def test_c3_full_batch_properties():
+    """BASELINE C3 at full size (10 000 read pairs, core global +5/-4, 10/1): size-independent properties --
+    every pair OK, global coords, score == recomputed score of the returned alignment, strings consistent."""
+    b = workloads.c3_batch(10000)
+    S = nucleotide_matrix()
+    got = align_batch(b, _ffi.CORE_GLOBAL, 10, 1, S)
+    r = got.results
+    assert (r["status"] == 0).all() and (r["f"] == 0.0).all()
+    assert (r["end_y"] == 150).all() and (r["end_x"] == 150).all() and (r["start_y"] == 0).all() and (r["start_x"] == 0).all()
+    for i in range(0, 10000, 97):
+        qa, ta = got.aligned(i)
+        # the duplicated seed pair closes both strings (simple/mod.rs:102-105)
+        assert qa[-1] == b.query(i)[-1] and ta[-1] == b.target(i)[-1]
+        body_q, body_t = qa[:-1], ta[:-1]
+        assert (body_q[body_q != 98] == b.query(i)).all() and (body_t[body_t != 98] == b.target(i)).all()
+        assert not ((body_q == 98) & (body_t == 98)).any()
+
+
+def test_summary_gather_on_gpu(blosum62):
+    """The records bench.py gathers with RCCL: device pointer -> torch tensor (no copy) -> all_gather (world size 1)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from aligner_amd.batch import RESULT_DTYPE, StagedBatch
+    from aligner_amd.distributed import SummaryGather, device_bytes_as_tensor, lpt_shards
+    b = workloads.c5_batch(n_pairs=200, lo=30, hi=200)
+    sb = StagedBatch(b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        sb.run(stream.cuda_stream)
+    torch.cuda.synchronize()
+    host = sb.fetch(False).results
+    view = device_bytes_as_tensor(sb.results_device_ptr, len(b) * RESULT_DTYPE.itemsize)
+    assert (view.cpu().numpy().view(RESULT_DTYPE) == host).all()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        shards = lpt_shards(b.q_len.astype(np.int64) * b.t_len.astype(np.int64), 1)
+        g = SummaryGather([len(s) for s in shards], 0, "cuda")
+        with torch.cuda.stream(stream):
+            g(view)
+        torch.cuda.synchronize()
+        assert (g.unpack(shards, len(b)) == host).all()
+    finally:
+        dist.destroy_process_group()
+    sb.close()
