@@ -62,6 +62,7 @@ struct FillArgs {
     int32_t semantics;
     uint32_t max_passes;
     uint32_t force_serial;
+    uint32_t store_dirs;      // 0: score-only run (no direction stores, no traceback)
     uint32_t no_repair;       // 1: disable the localized strip-0 repair (testing: full re-fills only)
     uint32_t ck_bytes;        // fast path: bytes of the checkpoint + strip-0 bottom-row areas in each wave's scratch
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
@@ -86,6 +87,7 @@ struct SingleArgs {
     int32_t semantics;
     uint32_t R, ns, pass, max_passes;
     uint32_t hazard;
+    uint32_t store_dirs;
 };
 
 struct TraceArgs {

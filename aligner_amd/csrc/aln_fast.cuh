@@ -108,6 +108,7 @@ struct FastIn {
     uint8_t *advice, *zrow;
     int *ckpt;
     bool hazard;
+    bool store_dirs;          // false: score-only (the packed directions are not written)
     int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair
     uint32_t last_flip;
     uint16_t *qo_pad;         // single-pair kernel: LDS, q[x] * 64R at index x + 63, zeros elsewhere (N + 192 entries)
@@ -334,7 +335,7 @@ struct FastStrip {
             else if (j == 2) v.z = dw;
             else v.w = dw;
         }
-        dirq[(size_t)(kb >> 2) * 64] = v;
+        if (in.store_dirs) dirq[(size_t)(kb >> 2) * 64] = v;
     }
 
     // folds the packed per-row candidates of the 2048-step chunk that starts at step `base` into the lane candidate

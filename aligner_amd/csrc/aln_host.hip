@@ -46,6 +46,7 @@ struct aln_batch {
     aln_params params{};
     size_t n = 0;
     bool is_int = true;
+    bool store_dirs = true;   // false: score-only batch (outputs has neither TRACEBACK nor DIRECTIONS)
     bool fast = false;        // integer kernels with the LDS query profile + packed max3 keys
     uint32_t prof_stride = 0;
     uint64_t cells = 0;
@@ -242,6 +243,10 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     b->fast = b->is_int && !want_h && !p->force_serial && !p->force_generic && cols <= 64 && smin >= -31.0 && smax <= 32.0 &&
               maxabs * (double)max_span < 268435456.0;
 
+    {
+        const uint32_t outs = p->outputs ? p->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
+        b->store_dirs = (outs & (ALN_OUT_TRACEBACK | ALN_OUT_DIRECTIONS)) != 0;
+    }
     // ---- routing + HBM layout.  A pair goes to the single-pair kernel (one wave per strip, strips pipelined across
     // CUs) when it is large, or when the batch is too small to fill the chip with one wave per pair.
     uint64_t dir_total = 0, tb_total = 0, hm_total = 0;
@@ -272,9 +277,11 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
             }
         }
         d.dir_off = dir_total;
-        dir_total += dbytes;
-        d.tb_off = tb_total;
-        tb_total += 3ull * ((uint64_t)d.N + d.M + 2);   // aligned query, aligned target, traceback tag scratch
+        if (b->store_dirs) {
+            dir_total += dbytes;
+            d.tb_off = tb_total;
+            tb_total += 3ull * ((uint64_t)d.N + d.M + 2);
+        }   // aligned query, aligned target, traceback tag scratch
         if (want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
     }
     b->dir_bytes = dir_total;
@@ -388,6 +395,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
     fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
     fa.no_repair = getenv("ALN_NO_REPAIR") ? 1u : 0u;
+    fa.store_dirs = b->store_dirs ? 1u : 0u;
     fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
     hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], s));
@@ -409,6 +417,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         sa.semantics = b->params.semantics; sa.R = b->single_r[j];
         sa.ns = (d.M + 64 * sa.R - 1) / (64 * sa.R);
         sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
+        sa.store_dirs = b->store_dirs ? 1u : 0u;
         sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
         const uint32_t lds = (uint32_t)(((uint64_t)sa.rows * sa.cols * 4 + 15) & ~15ull) + ((sa.cols * 64u * sa.R + 15u) & ~15u) +
                              (((d.N + 192u) * 2u + 15u) & ~15u) + 512u;
@@ -423,7 +432,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], s));
     const uint32_t outs = b->params.outputs ? b->params.outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
-    if (outs & ALN_OUT_TRACEBACK) {
+    if ((outs & ALN_OUT_TRACEBACK) && b->store_dirs) {
         TraceArgs ta{};
         ta.seqs = b->d_seqs; ta.descs = b->d_descs; ta.n_pairs = (uint32_t)b->n; ta.dirs = b->d_dirs;
         ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code;
@@ -543,6 +552,7 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
     aln_params p = *params;
     p.outputs = (params->outputs ? params->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK));
     if (q_aln && t_aln) p.outputs |= ALN_OUT_TRACEBACK;
+    if (directions) p.outputs |= ALN_OUT_DIRECTIONS;
     aln_batch *b = nullptr;
     int st = batch_build(ctx, &p, seqs.data(), &qo, &ql, &to, &tl, 1, h_matrix != nullptr, &b);
     if (st != ALN_OK) { memset(out, 0, sizeof *out); out->status = st; return st; }

@@ -109,6 +109,7 @@ struct Wave {
     uint8_t *advice, *zrow;   // row-1 penalty advice / observed bottom-row zeros
     SC *hmat;                 // optional H dump for this pair
     bool hazard;
+    bool store_dirs;          // false: score-only
     // running end-cell candidate of this lane (local semantics) and final corner value (global)
     SC bv; uint32_t by, bx;
     SC corner;
@@ -222,7 +223,7 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
                 }
             }
         }
-        dirw[aln_dir_word_index(kb * SPB, (uint32_t)lane, SPB)] = dw;   // quad layout of the fast path (aln_device.h)
+        if (w.store_dirs) dirw[aln_dir_word_index(kb * SPB, (uint32_t)lane, SPB)] = dw;   // quad layout of the fast path (aln_device.h)
     }
 
     // fold this strip's per-row candidates into the lane's running end-cell candidate
@@ -276,8 +277,10 @@ __device__ __noinline__ void serial_fill_impl(Wave<SC> &w)
             top = h;
             uint8_t *bp = dirs + (size_t)y * rowbytes + (x >> 2);
             const uint32_t sh = 2 * (x & 3u);
-            uint8_t old = (x == 1 || (x & 3u) == 0) ? 0 : *bp;
-            *bp = (uint8_t)(old | (d << sh));
+            if (w.store_dirs) {
+                uint8_t old = (x == 1 || (x & 3u) == 0) ? 0 : *bp;
+                *bp = (uint8_t)(old | (d << sh));
+            }
             if (is_local<SEM>() && better<SC, SEM>(h, y, x, bv, by, bx)) { bv = h; by = y; bx = x; }
             if (w.hmat != nullptr) w.hmat[(size_t)y * (N + 1) + x] = h;
         }
@@ -295,7 +298,7 @@ __device__ __forceinline__ void serial_fill(Wave<SC> &w)
 {
     Wave<SC> c;
     c.lane = 0; c.N = w.N; c.M = w.M; c.q = w.q; c.t = w.t; c.S = w.S; c.cols = w.cols; c.del = w.del; c.ext = w.ext;
-    c.dirw = w.dirw; c.brow = w.brow; c.hmat = w.hmat;
+    c.dirw = w.dirw; c.brow = w.brow; c.hmat = w.hmat; c.store_dirs = w.store_dirs;
     serial_fill_impl<SC, SEM>(c);
     w.bv = c.bv; w.by = c.by; w.bx = c.bx; w.corner = c.corner;
 }
@@ -353,6 +356,7 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
     w.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
     w.hmat = a.hmat ? reinterpret_cast<SC *>(a.hmat) + desc.h_off : nullptr;
     w.hazard = (SEM == ALN_CORE_LOCAL) && (w.del != w.ext) && N >= 2;
+    w.store_dirs = a.store_dirs != 0;
     if (w.hmat != nullptr) {   // borders of the optional H dump (simple/mod.rs:55-70)
         for (uint32_t x = lane; x <= N; x += 64) w.hmat[x] = border_top<SC, SEM>(x, N, w.del);
         for (uint32_t y = lane; y <= M; y += 64) w.hmat[(size_t)y * (N + 1)] = border_left<SC, SEM>(y, M, w.del);
@@ -428,6 +432,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
     in.hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
     in.ck_mode = 0; in.last_flip = 0;
+    in.store_dirs = a.store_dirs != 0;
     if (in.hazard)
         for (uint32_t x = lane; x <= N + 1; x += 64) { in.advice[x] = 0; in.zrow[x] = 0; }
     __threadfence_block();
@@ -473,7 +478,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     if (!converged) {                                    // strict reference order (exact for every input)
         Wave<int> c;
         c.lane = 0; c.N = N; c.M = M; c.q = in.q; c.t = in.t; c.S = in.S; c.cols = in.cols; c.del = del; c.ext = ext;
-        c.dirw = in.dirw; c.brow = in.brow; c.hmat = nullptr;
+        c.dirw = in.dirw; c.brow = in.brow; c.hmat = nullptr; c.store_dirs = in.store_dirs;
         c.bv = 0; c.by = 0; c.bx = 0; c.corner = 0;
         if (lane == 0) serial_fill_impl<int, SEM>(c);
         __threadfence_block();
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
     in.nd4 = -4 * (int)a.del;
     in.ne4 = -4 * (int)a.ext;
     in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr; in.qo_pad = nullptr; in.bring = nullptr;
-    in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.ck_mode = 0; in.last_flip = 0;
+    in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.store_dirs = true; in.ck_mode = 0; in.last_flip = 0;
     uint32_t pair;
     while (next_pair(a, in.lane, pair)) {
         PairDesc &desc = a.descs[pair];
@@ -603,6 +608,7 @@ __global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
     in.brow = nullptr; in.brow0 = nullptr; in.ckpt = nullptr;
     in.advice = a.advice; in.zrow = a.zrow;
     in.hazard = a.hazard != 0;
+    in.store_dirs = a.store_dirs != 0;
     in.ck_mode = 0; in.last_flip = 0;
     const uint32_t strip = blockIdx.x;
     const bool last = strip + 1 == a.ns;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(64) void aln_single_serial_kernel(SingleArgs a)
     w.S = S; w.cols = a.cols; w.del = (int)a.del; w.ext = (int)a.ext;
     w.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
     w.brow = reinterpret_cast<int *>(a.granules);
-    w.hmat = nullptr;
+    w.hmat = nullptr; w.store_dirs = a.store_dirs != 0;
     serial_fill_impl<int, SEM>(w);
     desc.layout = ALN_LAYOUT_ROWMAJOR;
     write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, desc.N, desc.M, a.ctrl[15] | 0x80u, 1u);

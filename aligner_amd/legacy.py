@@ -43,8 +43,8 @@ class LocalAlignmentResult(_LegacyResult):
 
 
 class SimpleAligner:
-    """aligner_core.rs:72-77.  from_seqs takes the raw FASTA bytes; bytes that are not residues are dropped, as the
-    8x11 golden matrices for "PAWHEAE---" show (the converter lives in a module missing from the reference tree)."""
+    """aligner_core.rs:72-77.  from_seqs takes the raw FASTA record bytes (`seqs[i].seq`, test_alignment.rs:80-81); the
+    u8 -> Protein converter lives in a module missing from the reference tree -- bytes outside the alphabet are dropped."""
 
     def __init__(self, seq_1, seq_2):
         self.u8_sequence_1 = bytes(seq_1)

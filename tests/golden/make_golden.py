@@ -3,8 +3,7 @@
 Reads /root/reference/src/tests/test_alignment.rs AS TEXT (the reference is Rust and cannot be built or
 imported here) and transcribes the literal expected matrices / alignments it holds (test_alignment.rs:14-67
 global, :106-159 local) into a JSON fixture.  Only data is extracted -- numbers, Direction names, Protein
-names -- no reference source text is kept.  Inputs come from examples/book_example_1.fasta
-(second record "PAWHEAE---": the legacy loader keeps only the 7 residues, as the 8x11 golden matrices show).
+names -- no reference source text is kept.  Inputs come from examples/book_example_1.fasta (HEAGAWGHEE / PAWHEAE).
 
 BLOSUM50 itself is not in the reference tree (load_blosum50 belongs to a missing module); the 6x6 sub-table
 over {A,E,G,H,P,W} below is the standard NCBI BLOSUM50 restricted to the residues of this example.  It is
@@ -65,7 +64,7 @@ def main():
     fasta = open("/root/reference/examples/book_example_1.fasta").read().split(">")[1:]
     seqs = ["".join(r.splitlines()[1:]) for r in fasta]
     query = seqs[0]
-    target = "".join(c for c in seqs[1] if c in PROT)   # drops the '-' padding
+    target = "".join(c for c in seqs[1] if c in PROT)
     m = [[0] * 24 for _ in range(24)]
     for (a, b), v in B50_SUB.items():
         m[PROT[a]][PROT[b]] = v

@@ -52,7 +52,7 @@ def test_device_is_mi355x():
 # ---------------------------------------------------------------- the reference's own known answers
 def test_kat_legacy_global_on_gpu(kat):
     """src/tests/test_alignment.rs:9-99 through SimpleAligner.global_alignment."""
-    r = SimpleAligner.from_seqs(b"HEAGAWGHEE", b"PAWHEAE---").global_alignment(8, kat["matrix"])
+    r = SimpleAligner.from_seqs(b"HEAGAWGHEE", b"PAWHEAE").global_alignment(8, kat["matrix"])
     assert (r.get_alignment_matrix() == np.array(kat["global"]["H"])).all()
     assert (r.get_direction_matrix() == np.array(kat["global"]["D"])).all()
     assert r.get_optimal_alignment()[0].tolist() == kat["global"]["query_aligned"]
@@ -61,7 +61,7 @@ def test_kat_legacy_global_on_gpu(kat):
 
 def test_kat_legacy_local_on_gpu(kat):
     """src/tests/test_alignment.rs:101-191 through SimpleAligner.local_alignment."""
-    r = SimpleAligner.from_seqs(b"HEAGAWGHEE", b"PAWHEAE---").local_alignment(8, kat["matrix"])
+    r = SimpleAligner.from_seqs(b"HEAGAWGHEE", b"PAWHEAE").local_alignment(8, kat["matrix"])
     assert (r.get_alignment_matrix() == np.array(kat["local"]["H"])).all()
     assert (r.get_direction_matrix() == np.array(kat["local"]["D"])).all()
     assert r.get_optimal_alignment()[0].tolist() == kat["local"]["query_aligned"]
@@ -301,3 +301,51 @@ def test_summary_gather_on_gpu(blosum62):
     finally:
         dist.destroy_process_group()
     sb.close()
+
+
+# ---------------------------------------------------------------- callers either side of the path
+def test_score_only_batch_equals_full_batch(blosum62):
+    b = workloads.c5_batch(n_pairs=400, lo=50, hi=900)
+    full = align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    score_only = align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62, want_traceback=False)
+    for k in ("f", "score", "end_y", "end_x", "status"):
+        assert (full.results[k] == score_only.results[k]).all(), k
+
+
+def test_p_value_batch_driver(orc, blosum62):
+    """calculate_p_value's batch (statistics/mod.rs:255-286): 4 999 shuffled targets, score only, one GPU batch; the
+    scores equal the oracle's on the same shuffles."""
+    from aligner_amd import statistics
+    rng = np.random.default_rng(2024)
+    q = rng.integers(0, 20, 180).astype(np.uint8)
+    t = np.concatenate([q[20:150], rng.integers(0, 20, 60).astype(np.uint8)])
+    init = orc.align(orc.CORE_LOCAL, q, t, 11, 2, blosum62)["f"]
+    scores, lengths, batch = statistics.shuffled_scores(q, t, init, 11, 2, blosum62, rng=np.random.default_rng(7))
+    assert len(scores) == len(lengths) == 5000 and len(batch) == 4999
+    assert scores[0] == init and lengths[0] == len(t) and (lengths[1:] >= len(t) - 6).all()
+    ref, _, _ = orc.align_batch(orc.CORE_LOCAL, batch.seqs, batch.q_off, batch.q_len, batch.t_off, batch.t_len, 11, 2,
+                                blosum62, n_threads=8, want_traceback=False)
+    assert all(ref[i].f == scores[i + 1] for i in range(len(batch)))
+    p = statistics.calculate_p_value(q, t, init, 11, 2, blosum62, rng=np.random.default_rng(7))
+    assert 0.0 <= p <= 1.0 and p < 0.05          # a 130-residue exact match is not a chance hit
+
+
+def test_cli_on_reference_example(orc, blosum62, capsys, tmp_path):
+    import os
+    from aligner_amd import cli
+    from aligner_amd.fasta import encode_records, read_fasta
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "protein.fasta")
+    q, t = encode_records(read_fasta(path), Protein)
+    for flag, sem in (([], orc.CORE_LOCAL), (["-g"], orc.CORE_GLOBAL)):
+        assert cli.main(["-i", path] + flag) == 0
+        out = capsys.readouterr().out.strip()
+        ref = orc.align(sem, q, t, 11, 2, blosum62)
+        assert out == cli.debug_vec(orc.midline(ref["qa"], ref["ta"], blosum62))
+    # SURVEY Appendix B anchor: f = 1554 on this pair
+    assert orc.align(orc.CORE_LOCAL, q, t, 11, 2, blosum62)["f"] == 1554.0
+    # C1 plumbing: the book example through the CLI, both modes (SURVEY Appendix B anchors)
+    book = os.path.join(os.path.dirname(path), "book_example_1.fasta")
+    assert cli.main(["-i", book]) == 0
+    assert capsys.readouterr().out.strip() == "[Blank, A, W, Blank, H, E, Blank, E, E]"
+    assert cli.main(["-i", book, "-g"]) == 0
+    assert capsys.readouterr().out.strip() == "[Blank, Blank, A, Blank, Blank, W, Blank, H, E, Blank, E, E]"
