@@ -12,10 +12,11 @@ from .enums import DNA, Direction, Protein
 from .errors import AlignerError, DeviceError, ErrorKind, ReferencePanic
 from .legacy import SimpleAligner
 from .matrices import get_blosum62, nucleotide_matrix
+from .pwm import PWMAligner, PWMAlignment, align_windows
 from .simple import Heuristics, SimpleGlobalAligner, SimpleLocalAligner
 
 __all__ = [
     "Alignment", "AlignmentResult", "BatchResult", "PairBatch", "StagedBatch", "align_batch", "DNA", "Direction",
     "Protein", "AlignerError", "DeviceError", "ErrorKind", "ReferencePanic", "SimpleAligner", "get_blosum62",
-    "nucleotide_matrix", "Heuristics", "SimpleGlobalAligner", "SimpleLocalAligner",
+    "nucleotide_matrix", "PWMAligner", "PWMAlignment", "align_windows", "Heuristics", "SimpleGlobalAligner", "SimpleLocalAligner",
 ]

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ALN_LIB") or os.path.join(_HERE, "lib", "libaligner_hip.so")
 
 # enum aln_semantics
-CORE_GLOBAL, CORE_LOCAL, LEGACY_GLOBAL, LEGACY_LOCAL = 0, 1, 2, 3
+CORE_GLOBAL, CORE_LOCAL, LEGACY_GLOBAL, LEGACY_LOCAL, PWM_LOCAL = 0, 1, 2, 3, 4
 # enum aln_status
 OK = 0
 ERR_UNNECESSARY_ARGUMENT = 1
@@ -21,9 +21,10 @@ ERR_DEVICE = 5
 ERR_OOM = 6
 ERR_INVALID_ARGUMENT = 7
 ERR_UNSUPPORTED = 8
+ERR_MATRIX_SHAPE = 9
 STATUS_NAMES = {0: "OK", 1: "ERR_UNNECESSARY_ARGUMENT", 2: "ERR_EMPTY_SEQUENCE", 3: "ERR_CODE_OUT_OF_RANGE",
                 4: "ERR_NO_POSITIVE_CELL", 5: "ERR_DEVICE", 6: "ERR_OOM", 7: "ERR_INVALID_ARGUMENT",
-                8: "ERR_UNSUPPORTED"}
+                8: "ERR_UNSUPPORTED", 9: "ERR_MATRIX_SHAPE"}
 # enum aln_outputs
 OUT_SCORE, OUT_TRACEBACK, OUT_DIRECTIONS, OUT_H_MATRIX = 1, 2, 4, 8
 

@@ -63,6 +63,8 @@ struct FillArgs {
     uint32_t max_passes;
     uint32_t force_serial;
     uint32_t store_dirs;      // 0: score-only run (no direction stores, no traceback)
+    uint32_t pwm;             // 1: position-weight-matrix scoring: S[t[y-1]][x-1], the query codes are the column indices
+    const uint32_t *pwm_words;// fast path: per column the four int8 scores 4*s - 2 of residues 0..3, packed
     uint32_t no_repair;       // 1: disable the localized strip-0 repair (testing: full re-fills only)
     uint32_t ck_bytes;        // fast path: bytes of the checkpoint + strip-0 bottom-row areas in each wave's scratch
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
@@ -99,6 +101,7 @@ struct TraceArgs {
     uint8_t *tb;
     int32_t semantics;
     uint8_t blank;
+    uint8_t pwm;
 };
 
 // Parallel traceback of one large pair (uniform-R layout): per strip and entry column an "exit map", then a short

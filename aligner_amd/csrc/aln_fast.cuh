@@ -109,6 +109,8 @@ struct FastIn {
     int *ckpt;
     bool hazard;
     bool store_dirs;          // false: score-only (the packed directions are not written)
+    bool pwm;                 // position-weight-matrix scoring (batch kernels only)
+    const uint32_t *pwm_words;// per column: int8 scores 4*s - 2 of residues 0..3
     int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair
     uint32_t last_flip;
     uint16_t *qo_pad;         // single-pair kernel: LDS, q[x] * 64R at index x + 63, zeros elsewhere (N + 192 entries)
@@ -164,6 +166,15 @@ struct FastStrip {
     __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s)
         : in(i), strip(s), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
 
+    // PWM scoring: the flowing register holds the column's four packed scores; one v_perm per four rows picks each
+    // row's byte by its residue code -- the result has the layout of a profile read
+    uint32_t psel_lo, psel_hi;
+    __device__ __forceinline__ PW pwm_select(uint32_t w4) const
+    {
+        if constexpr (R == 8) return make_uint2(__builtin_amdgcn_perm(w4, w4, psel_lo), __builtin_amdgcn_perm(w4, w4, psel_hi));
+        else return (PW)__builtin_amdgcn_perm(w4, w4, psel_lo);
+    }
+
     // next 64 columns of the row above this strip (T form), one per lane
     __device__ __forceinline__ int load_boundary(uint32_t xi)
     {
@@ -198,7 +209,7 @@ struct FastStrip {
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
             if (!FIRST && !SINGLE) inchunk = load_boundary(xi);
             if (SEM == ALN_CORE_LOCAL && FIRST && in.hazard) advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
-            if (!SINGLE) qchunk = (xi + 1 < N) ? (int)in.q[xi + 1] * (64 * R) : 0;
+            if (!SINGLE) qchunk = (xi + 1 < N) ? (in.pwm ? (int)in.pwm_words[xi + 1] : (int)in.q[xi + 1] * (64 * R)) : 0;
         }
         const int sel = (int)(k & 63u);
         int top0;
@@ -216,7 +227,7 @@ struct FastStrip {
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 2));         // step k+2
         } else {
             qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);             // next step's query code reaches every lane
-            pw = *reinterpret_cast<const PW *>(prow + qoff);
+            pw = in.pwm ? pwm_select((uint32_t)qoff) : *reinterpret_cast<const PW *>(prow + qoff);
         }
         // end-cell tie-break term of this step: earlier steps win (core) / later steps win (legacy)
         const int kterm = (SEM == ALN_CORE_LOCAL) ? (int)(2047u - (k & 2047u)) : (int)(k & 2047u);
@@ -394,7 +405,14 @@ struct FastStrip {
             Tl[r] = LOCAL ? 2 : (y == M ? 2 + (int)(M + 1) * in.nd4 : 2 + (int)y * in.nd4);
             rbv[r] = INT_MIN;
         }
-        for (uint32_t c = 0; c < in.cols; ++c) {
+        psel_lo = 0; psel_hi = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                       // PWM: byte selectors = the rows' residue codes (0..3)
+            const uint32_t y = yb + 1 + r;
+            const uint32_t code = (y <= M) ? (uint32_t)in.t[y - 1] & 3u : 0u;
+            if (r < 4) psel_lo |= code << (8 * r); else psel_hi |= code << (8 * (r - 4));
+        }
+        for (uint32_t c = 0; c < (in.pwm ? 0u : in.cols); ++c) {
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -418,9 +436,10 @@ struct FastStrip {
             qoff = *reinterpret_cast<const uint16_t *>(qo_lane);                      // step 0: column -lane
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2);                    // step 1
         } else {
-            qoff = (lane == 0) ? (int)in.q[0] * (64 * R) : 0;
+            qoff = (lane == 0) ? (in.pwm ? (int)in.pwm_words[0] : (int)in.q[0] * (64 * R)) : 0;
         }
-        pw = *reinterpret_cast<const PW *>(prow + qoff);
+        if (!SINGLE && in.pwm) pw = pwm_select((uint32_t)qoff);
+        else pw = *reinterpret_cast<const PW *>(prow + qoff);
 
         // directions: four blocks per lane per 16-byte store (aln_device.h); all segment ends are whole quads
         uint4 *dirq = reinterpret_cast<uint4 *>(in.dirw) +

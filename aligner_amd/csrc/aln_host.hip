@@ -46,6 +46,8 @@ struct aln_batch {
     aln_params params{};
     size_t n = 0;
     bool is_int = true;
+    bool pwm = false;         // ALN_PWM_LOCAL: kernels run as CORE_LOCAL with position-specific scoring
+    uint32_t *d_pwm_words = nullptr;
     bool store_dirs = true;   // false: score-only batch (outputs has neither TRACEBACK nor DIRECTIONS)
     bool fast = false;        // integer kernels with the LDS query profile + packed max3 keys
     uint32_t prof_stride = 0;
@@ -162,7 +164,7 @@ static void batch_free(aln_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     void *ptrs[] = {b->d_seqs, b->d_descs, b->d_order, b->d_counter, b->d_dirs, b->d_results, b->d_tb, b->d_scratch,
-                    b->d_matrix, b->d_hmat, b->d_granules, b->d_advice1, b->d_cand, b->d_ctrl, b->d_tbmap};
+                    b->d_matrix, b->d_hmat, b->d_granules, b->d_advice1, b->d_cand, b->d_ctrl, b->d_tbmap, b->d_pwm_words};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -176,11 +178,13 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
 {
     *out = nullptr;
     if (!ctx || !p || (n && (!seqs || !q_off || !q_len || !t_off || !t_len))) { g_err = "null argument"; return ALN_ERR_INVALID_ARGUMENT; }
-    if (p->semantics < ALN_CORE_GLOBAL || p->semantics > ALN_LEGACY_LOCAL) { g_err = "bad semantics"; return ALN_ERR_INVALID_ARGUMENT; }
-    const bool core = p->semantics == ALN_CORE_GLOBAL || p->semantics == ALN_CORE_LOCAL;
+    if (p->semantics < ALN_CORE_GLOBAL || p->semantics > ALN_PWM_LOCAL) { g_err = "bad semantics"; return ALN_ERR_INVALID_ARGUMENT; }
+    const bool pwm = p->semantics == ALN_PWM_LOCAL;
+    const bool core = p->semantics == ALN_CORE_GLOBAL || p->semantics == ALN_CORE_LOCAL || pwm;
     // simple/mod.rs:49-51 / :175-177
     if (core && p->heuristics_present) return ALN_ERR_UNNECESSARY_ARGUMENT;
     if (!p->matrix || p->rows == 0 || p->cols == 0) { g_err = "matrix missing"; return ALN_ERR_INVALID_ARGUMENT; }
+    if (pwm && p->rows != 4) return ALN_ERR_MATRIX_SHAPE;                      // pwm/mod.rs:40-42
     if ((uint64_t)p->rows * p->cols > 4096) { g_err = "substitution matrix larger than 4096 entries"; return ALN_ERR_UNSUPPORTED; }
     if (n > 0xFFFFFFF0ull) { g_err = "too many pairs"; return ALN_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(ctx->device));
@@ -190,6 +194,8 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     b->params = *p;
     b->params.matrix = nullptr;
     b->n = n;
+    b->pwm = pwm;
+    if (pwm) b->params.semantics = ALN_CORE_LOCAL;   // same recurrence and tie rules; only the score lookup differs
 
     // ---- compact the matrix, pick the arithmetic
     const uint32_t rows = p->rows, cols = p->cols;
@@ -218,13 +224,13 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
         d.q_off = q_off[i];
         d.t_off = t_off[i];
         if (q_len[i] > 0x7FFFFFF0ull || t_len[i] > 0x7FFFFFF0ull) { g_err = "sequence too long"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
-        d.N = (uint32_t)q_len[i];
+        d.N = pwm ? cols : (uint32_t)q_len[i];                                 // PWM: the columns are the PWM positions
         d.M = (uint32_t)t_len[i];
         d.status = ALN_OK;
-        if (d.N == 0 || d.M == 0) d.status = ALN_ERR_EMPTY_SEQUENCE;          // reference panics
+        if (d.N == 0 || d.M == 0) d.status = ALN_ERR_EMPTY_SEQUENCE;          // reference panics (PWM: treated alike)
         else {
             const uint8_t *q = seqs + d.q_off, *t = seqs + d.t_off;
-            for (uint32_t k = 0; k < d.N && d.status == ALN_OK; ++k) if (q[k] >= cols) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
+            if (!pwm) for (uint32_t k = 0; k < d.N && d.status == ALN_OK; ++k) if (q[k] >= cols) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
             for (uint32_t k = 0; k < d.M && d.status == ALN_OK; ++k) if (t[k] >= rows) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
         }
         if (d.status != ALN_OK) continue;
@@ -240,7 +246,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     // fast integer kernels: keys are 4*H + tag in i32 and the profile holds 4*s - 1 as int8
     double smin = 0, smax = 0;
     for (double v : md) { smin = std::min(smin, v); smax = std::max(smax, v); }
-    b->fast = b->is_int && !want_h && !p->force_serial && !p->force_generic && cols <= 64 && smin >= -31.0 && smax <= 32.0 &&
+    b->fast = b->is_int && !want_h && !p->force_serial && !p->force_generic && (pwm || cols <= 64) && smin >= -31.0 && smax <= 32.0 &&
               maxabs * (double)max_span < 268435456.0;
 
     {
@@ -256,7 +262,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
         PairDesc &d = b->descs[i];
         if (d.status != ALN_OK) continue;
         const uint64_t pc = (uint64_t)d.N * d.M;
-        bool single = b->fast && !env_off && d.N >= 64 && d.M >= 128 && (pc >= (1ull << 24) || (n <= 16 && pc >= (1ull << 18)));
+        bool single = b->fast && !pwm && !env_off && d.N >= 64 && d.M >= 128 && (pc >= (1ull << 24) || (n <= 16 && pc >= (1ull << 18)));
         uint64_t dbytes = aln_dir_bytes(d.N, d.M);
         if (single) {
             uint32_t R = env_r ? (uint32_t)atoi(env_r) : (d.M > 4096 ? 2u : 1u);
@@ -280,7 +286,8 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
         if (b->store_dirs) {
             dir_total += dbytes;
             d.tb_off = tb_total;
-            tb_total += 3ull * ((uint64_t)d.N + d.M + 2);
+            // aligned query, aligned target, traceback tag scratch (PWM: u32 column numbers, residues, tags)
+            tb_total += ((pwm ? 6ull : 3ull) * ((uint64_t)d.N + d.M + 2) + 3) & ~3ull;
         }   // aligned query, aligned target, traceback tag scratch
         if (want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
     }
@@ -311,12 +318,12 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     const uint64_t ck_bytes = b->fast ? (4ull * 18 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
     b->scratch_stride = brow_bytes + 2 * adv_bytes + ck_bytes;
     b->lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
-    if (b->fast) { b->prof_stride = cols * 64u * ALN_FULL_R; b->lds_bytes += 4u * b->prof_stride; }
+    if (b->fast && !pwm) { b->prof_stride = cols * 64u * ALN_FULL_R; b->lds_bytes += 4u * b->prof_stride; }
 
     // ---- device allocations + H2D
     uint64_t seq_bytes = 0;
     for (size_t i = 0; i < n; ++i) {
-        seq_bytes = std::max(seq_bytes, q_off[i] + q_len[i]);
+        if (!pwm) seq_bytes = std::max(seq_bytes, q_off[i] + q_len[i]);
         seq_bytes = std::max(seq_bytes, t_off[i] + t_len[i]);
     }
     auto dmalloc = [&](void **ptr, uint64_t bytes) { return hipMalloc(ptr, std::max<uint64_t>(bytes, 256)); };
@@ -350,6 +357,16 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
         BCHK(hipMemcpy(b->d_matrix, mi.data(), mi.size() * 4, hipMemcpyHostToDevice));
     } else {
         BCHK(hipMemcpy(b->d_matrix, md.data(), md.size() * 8, hipMemcpyHostToDevice));
+    }
+    if (pwm && b->fast) {
+        std::vector<uint32_t> words(cols);
+        for (uint32_t c = 0; c < cols; ++c) {
+            uint32_t wv = 0;
+            for (uint32_t r = 0; r < 4; ++r) wv |= ((uint32_t)(int32_t)(4 * (int32_t)md[(size_t)r * cols + c] - 2) & 0xffu) << (8 * r);
+            words[c] = wv;
+        }
+        BCHK(dmalloc((void **)&b->d_pwm_words, (uint64_t)cols * 4));
+        BCHK(hipMemcpy(b->d_pwm_words, words.data(), (size_t)cols * 4, hipMemcpyHostToDevice));
     }
     BCHK(hipMemset(b->d_results, 0, std::max<uint64_t>(n * sizeof(aln_pair_result), 1)));
 #undef BCHK
@@ -396,6 +413,8 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
     fa.no_repair = getenv("ALN_NO_REPAIR") ? 1u : 0u;
     fa.store_dirs = b->store_dirs ? 1u : 0u;
+    fa.pwm = b->pwm ? 1u : 0u;
+    fa.pwm_words = b->d_pwm_words;
     fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
     hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], s));
@@ -435,7 +454,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     if ((outs & ALN_OUT_TRACEBACK) && b->store_dirs) {
         TraceArgs ta{};
         ta.seqs = b->d_seqs; ta.descs = b->d_descs; ta.n_pairs = (uint32_t)b->n; ta.dirs = b->d_dirs;
-        ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code;
+        ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code; ta.pwm = b->pwm ? 1 : 0;
         aln_launch_traceback(&ta, s);       // every pair except those in the uniform-R layout (handled below)
         for (size_t j = 0; j < b->single_pairs.size(); ++j) {
             const PairDesc &d = b->descs[b->single_pairs[j]];
@@ -495,8 +514,13 @@ extern "C" int aln_batch_fetch(aln_batch *b, aln_pair_result *results, uint8_t *
             const PairDesc &d = b->descs[i];
             if (results[i].status != ALN_OK) continue;
             const uint64_t cap = (uint64_t)d.N + d.M + 2;
-            memcpy(tb_buf + tb_off[i], h.data() + d.tb_off, results[i].aln_len);
-            memcpy(tb_buf + tb_off[i] + cap, h.data() + d.tb_off + cap, results[i].aln_len);
+            if (b->pwm) {   // u32 column numbers, then the residue string
+                memcpy(tb_buf + tb_off[i], h.data() + d.tb_off, 4ull * results[i].aln_len);
+                memcpy(tb_buf + tb_off[i] + 4 * cap, h.data() + d.tb_off + 4 * cap, results[i].aln_len);
+            } else {
+                memcpy(tb_buf + tb_off[i], h.data() + d.tb_off, results[i].aln_len);
+                memcpy(tb_buf + tb_off[i] + cap, h.data() + d.tb_off + cap, results[i].aln_len);
+            }
         }
     }
     return ALN_OK;
@@ -545,10 +569,13 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
                               uint8_t *directions, double *h_matrix)
 {
     if (!ctx || !params || !out) { g_err = "null argument"; return ALN_ERR_INVALID_ARGUMENT; }
-    std::vector<uint8_t> seqs(N + M + 1);
-    if (N) memcpy(seqs.data(), query, N);
-    if (M) memcpy(seqs.data() + N, target, M);
-    const uint64_t qo = 0, ql = N, to = N, tl = M;
+    const bool pwm = params->semantics == ALN_PWM_LOCAL;
+    if (pwm) { N = params->cols; query = nullptr; }          // the columns are the PWM positions (pwm/mod.rs:44-46)
+    const size_t nq = pwm ? 0 : N;
+    std::vector<uint8_t> seqs(nq + M + 1);
+    if (nq) memcpy(seqs.data(), query, nq);
+    if (M) memcpy(seqs.data() + nq, target, M);
+    const uint64_t qo = 0, ql = N, to = nq, tl = M;
     aln_params p = *params;
     p.outputs = (params->outputs ? params->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK));
     if (q_aln && t_aln) p.outputs |= ALN_OUT_TRACEBACK;
@@ -558,13 +585,19 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
     if (st != ALN_OK) { memset(out, 0, sizeof *out); out->status = st; return st; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     st = aln_batch_run(b, nullptr);
-    std::vector<uint8_t> tb(2 * (N + M + 2));
+    const size_t cap = N + M + 2;
+    std::vector<uint8_t> tb((pwm ? 5 : 2) * cap + 8);
     const uint64_t tbo = 0;
     if (st == ALN_OK) st = aln_batch_fetch(b, out, tb.data(), &tbo);
     if (st == ALN_OK && out->status == ALN_OK) {
         if (q_aln && t_aln) {
-            memcpy(q_aln, tb.data(), out->aln_len);
-            memcpy(t_aln, tb.data() + (N + M + 2), out->aln_len);
+            if (pwm) {
+                memcpy(q_aln, tb.data(), 4ull * out->aln_len);          // uint32 PWM column numbers
+                memcpy(t_aln, tb.data() + 4 * cap, out->aln_len);
+            } else {
+                memcpy(q_aln, tb.data(), out->aln_len);
+                memcpy(t_aln, tb.data() + cap, out->aln_len);
+            }
         }
         const uint64_t cells = (uint64_t)(N + 1) * (M + 1);
         if (directions) {
@@ -572,7 +605,7 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
             hipError_t e = hipMalloc((void **)&d_out, cells);
             if (e != hipSuccess) { st = fail(e, "hipMalloc(directions)"); }
             else {
-                aln_launch_unpack(b->d_dirs, b->d_descs, 0, p.semantics, d_out, cells, b->ctx->stream);
+                aln_launch_unpack(b->d_dirs, b->d_descs, 0, b->params.semantics, d_out, cells, b->ctx->stream);
                 e = hipStreamSynchronize(b->ctx->stream);
                 if (e == hipSuccess) e = hipMemcpy(directions, d_out, cells, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) st = fail(e, "unpack directions");

@@ -110,6 +110,7 @@ struct Wave {
     SC *hmat;                 // optional H dump for this pair
     bool hazard;
     bool store_dirs;          // false: score-only
+    bool pwm;                 // position-weight-matrix scoring: column index instead of a query residue
     // running end-cell candidate of this lane (local semantics) and final corner value (global)
     SC bv; uint32_t by, bx;
     SC corner;
@@ -181,7 +182,7 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
             const uint32_t xm1 = k - (uint32_t)lane;  // x - 1 (wraps for lanes that have not started)
             if (xm1 < N) {
                 const uint32_t x = xm1 + 1;
-                const int qc = w.q[xm1];
+                const int qc = w.pwm ? (int)xm1 : (int)w.q[xm1];
                 SC top = topIn, diag = hdiag;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -260,7 +261,7 @@ __device__ __noinline__ void serial_fill_impl(Wave<SC> &w)
     SC bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : ScOps<SC>::lowest();
     uint32_t by = 0, bx = 0;
     for (uint32_t x = 1; x <= N; ++x) {
-        const int qc = w.q[x - 1];
+        const int qc = w.pwm ? (int)(x - 1) : (int)w.q[x - 1];
         SC diag = col[0];
         col[0] = border_top<SC, SEM>(x, N, del);
         SC top = col[0];
@@ -298,7 +299,7 @@ __device__ __forceinline__ void serial_fill(Wave<SC> &w)
 {
     Wave<SC> c;
     c.lane = 0; c.N = w.N; c.M = w.M; c.q = w.q; c.t = w.t; c.S = w.S; c.cols = w.cols; c.del = w.del; c.ext = w.ext;
-    c.dirw = w.dirw; c.brow = w.brow; c.hmat = w.hmat; c.store_dirs = w.store_dirs;
+    c.dirw = w.dirw; c.brow = w.brow; c.hmat = w.hmat; c.store_dirs = w.store_dirs; c.pwm = w.pwm;
     serial_fill_impl<SC, SEM>(c);
     w.bv = c.bv; w.by = c.by; w.bx = c.bx; w.corner = c.corner;
 }
@@ -323,7 +324,7 @@ __device__ __forceinline__ bool adopt_advice(uint8_t *advice, const uint8_t *zro
 // writes the fill-side half of the pair's summary (the traceback kernel adds start cell and length)
 template <int SEM>
 __device__ __forceinline__ void write_result(aln_pair_result &res, double best, uint32_t by, uint32_t bx, double corner,
-                                             uint32_t N, uint32_t M, uint32_t passes, uint32_t flags)
+                                             uint32_t N, uint32_t M, uint32_t passes, uint32_t flags, bool pwm = false)
 {
     res.passes = passes;
     res.flags = flags;
@@ -335,7 +336,11 @@ __device__ __forceinline__ void write_result(aln_pair_result &res, double best, 
         res.f = best;
         res.end_y = by; res.end_x = bx;
         // core local: the argmax runs over the zero borders too; a non-positive maximum sits on (0,0) (simple/mod.rs:212-215)
-        if (SEM == ALN_CORE_LOCAL && !(best > 0.0)) { res.status = ALN_ERR_NO_POSITIVE_CELL; res.end_y = res.end_x = 0; res.score = res.f = 0.0; }
+        if (SEM == ALN_CORE_LOCAL && !(best > 0.0)) {
+            // PWMAligner has no seed pair: an all-non-positive matrix is an empty alignment with f = 0 (pwm/mod.rs:76-108)
+            res.status = pwm ? ALN_OK : ALN_ERR_NO_POSITIVE_CELL;
+            res.end_y = res.end_x = 0; res.score = res.f = 0.0;
+        }
     } else {
         res.score = corner;
         res.f = (SEM == ALN_CORE_GLOBAL) ? 0.0 : corner;       // simple/mod.rs:139
@@ -357,6 +362,7 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
     w.hmat = a.hmat ? reinterpret_cast<SC *>(a.hmat) + desc.h_off : nullptr;
     w.hazard = (SEM == ALN_CORE_LOCAL) && (w.del != w.ext) && N >= 2;
     w.store_dirs = a.store_dirs != 0;
+    w.pwm = a.pwm != 0;
     if (w.hmat != nullptr) {   // borders of the optional H dump (simple/mod.rs:55-70)
         for (uint32_t x = lane; x <= N; x += 64) w.hmat[x] = border_top<SC, SEM>(x, N, w.del);
         for (uint32_t y = lane; y <= M; y += 64) w.hmat[(size_t)y * (N + 1)] = border_left<SC, SEM>(y, M, w.del);
@@ -411,7 +417,7 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
     }
     if (lane == 0) {
         desc.layout = layout;
-        write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, N, M, passes, sizeof(SC) == 4 ? 1u : 0u);
+        write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, N, M, passes, sizeof(SC) == 4 ? 1u : 0u, w.pwm);
     }
 }
 
@@ -433,6 +439,8 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     in.hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
     in.ck_mode = 0; in.last_flip = 0;
     in.store_dirs = a.store_dirs != 0;
+    in.pwm = a.pwm != 0;
+    in.pwm_words = a.pwm_words;
     if (in.hazard)
         for (uint32_t x = lane; x <= N + 1; x += 64) { in.advice[x] = 0; in.zrow[x] = 0; }
     __threadfence_block();
@@ -478,20 +486,20 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     if (!converged) {                                    // strict reference order (exact for every input)
         Wave<int> c;
         c.lane = 0; c.N = N; c.M = M; c.q = in.q; c.t = in.t; c.S = in.S; c.cols = in.cols; c.del = del; c.ext = ext;
-        c.dirw = in.dirw; c.brow = in.brow; c.hmat = nullptr; c.store_dirs = in.store_dirs;
+        c.dirw = in.dirw; c.brow = in.brow; c.hmat = nullptr; c.store_dirs = in.store_dirs; c.pwm = in.pwm;
         c.bv = 0; c.by = 0; c.bx = 0; c.corner = 0;
         if (lane == 0) serial_fill_impl<int, SEM>(c);
         __threadfence_block();
         if (lane == 0) {
             desc.layout = ALN_LAYOUT_ROWMAJOR;
-            write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, 1u);
+            write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, 1u, in.pwm);
         }
         return;
     }
     if (is_local<SEM>()) reduce_best<SEM>(o);
     if (lane == 0) {
         desc.layout = ALN_LAYOUT_SKEW;
-        write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)(o.corner >> 2), N, M, passes, 1u);
+        write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)(o.corner >> 2), N, M, passes, 1u, in.pwm);
     }
 }
 
@@ -572,7 +580,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
     in.nd4 = -4 * (int)a.del;
     in.ne4 = -4 * (int)a.ext;
     in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr; in.qo_pad = nullptr; in.bring = nullptr;
-    in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.store_dirs = true; in.ck_mode = 0; in.last_flip = 0;
+    in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.store_dirs = true; in.pwm = false; in.pwm_words = nullptr; in.ck_mode = 0; in.last_flip = 0;
     uint32_t pair;
     while (next_pair(a, in.lane, pair)) {
         PairDesc &desc = a.descs[pair];
@@ -609,6 +617,7 @@ __global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
     in.advice = a.advice; in.zrow = a.zrow;
     in.hazard = a.hazard != 0;
     in.store_dirs = a.store_dirs != 0;
+    in.pwm = false; in.pwm_words = nullptr;
     in.ck_mode = 0; in.last_flip = 0;
     const uint32_t strip = blockIdx.x;
     const bool last = strip + 1 == a.ns;
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(64) void aln_single_serial_kernel(SingleArgs a)
     w.S = S; w.cols = a.cols; w.del = (int)a.del; w.ext = (int)a.ext;
     w.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
     w.brow = reinterpret_cast<int *>(a.granules);
-    w.hmat = nullptr; w.store_dirs = a.store_dirs != 0;
+    w.hmat = nullptr; w.store_dirs = a.store_dirs != 0; w.pwm = false;
     serial_fill_impl<int, SEM>(w);
     desc.layout = ALN_LAYOUT_ROWMAJOR;
     write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, desc.N, desc.M, a.ctrl[15] | 0x80u, 1u);
@@ -833,9 +842,7 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     const uint8_t *__restrict__ q = a.seqs + d.q_off;
     const uint8_t *__restrict__ t = a.seqs + d.t_off;
     const uint32_t cap = d.N + d.M + 2;
-    uint8_t *__restrict__ qa = a.tb + d.tb_off;
-    uint8_t *__restrict__ ta = qa + cap;
-    uint8_t *__restrict__ ops = ta + cap;
+    uint8_t *__restrict__ ops = a.tb + d.tb_off + (a.pwm ? 5ull : 2ull) * cap;
     const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
     const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
     const uint32_t ey = res.end_y, ex = res.end_x, N = d.N;
@@ -870,7 +877,7 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
         }
     }
     res.start_y = cy; res.start_x = cx;
-    res.aln_len = len + 1;                              // + the duplicated seed pair, written by the expand kernel
+    res.aln_len = len + (a.pwm ? 0u : 1u);              // + the duplicated seed pair (none for the PWM aligner)
 }
 
 // ---------------------------------------------------------------- parallel traceback of one large pair
@@ -995,9 +1002,10 @@ extern "C" __global__ __launch_bounds__(256) void aln_traceback_expand_kernel(Tr
     const uint8_t *__restrict__ t = a.seqs + d.t_off;
     const uint32_t cap = d.N + d.M + 2;
     uint8_t *__restrict__ qa = a.tb + d.tb_off;
-    uint8_t *__restrict__ ta = qa + cap;
-    const uint8_t *__restrict__ ops = ta + cap;
-    const uint32_t len = res.aln_len - 1;
+    uint8_t *__restrict__ ta = qa + (a.pwm ? 4ull : 1ull) * cap;
+    const uint8_t *__restrict__ ops = a.tb + d.tb_off + (a.pwm ? 5ull : 2ull) * cap;
+    uint32_t *__restrict__ numbered = reinterpret_cast<uint32_t *>(qa);    // PWM: column numbers instead of query residues
+    const uint32_t len = res.aln_len - (a.pwm ? 0u : 1u);
     // output positions j in [lo, hi) belong to this lane; position j reads ops[len - 1 - j]
     const uint32_t per = (len + 63) / 64;
     const uint32_t lo = min(len, (uint32_t)lane * per), hi = min(len, lo + per);
@@ -1017,10 +1025,11 @@ extern "C" __global__ __launch_bounds__(256) void aln_traceback_expand_kernel(Tr
     for (uint32_t j = lo; j < hi; ++j) {
         const uint32_t tag = ops[len - 1 - j];
         px += (tag != 2u); py += (tag != 1u);           // the cell this step left
-        qa[j] = (tag == 2u) ? a.blank : q[px - 1];
+        if (a.pwm) numbered[j] = (tag == 2u) ? 0u : px;                    // pwm/mod.rs:86-101
+        else qa[j] = (tag == 2u) ? a.blank : q[px - 1];
         ta[j] = (tag == 1u) ? a.blank : t[py - 1];
     }
-    if (lane == 0) {
+    if (lane == 0 && !a.pwm) {
         qa[len] = q[res.end_x - 1];                     // simple/mod.rs:102-105, :213-216: the duplicated seed
         ta[len] = t[res.end_y - 1];
     }

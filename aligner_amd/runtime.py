@@ -52,6 +52,8 @@ def raise_for_status(st, where=""):
     name = _ffi.STATUS_NAMES.get(st, str(st))
     if st == _ffi.ERR_UNNECESSARY_ARGUMENT:
         raise AlignerError(ErrorKind.UnnecessaryArgument)          # simple/mod.rs:49-51
+    if st == _ffi.ERR_MATRIX_SHAPE:
+        raise AlignerError(ErrorKind.MatrixShapeError)             # pwm/mod.rs:40-42
     if st == _ffi.ERR_EMPTY_SEQUENCE:
         raise ReferencePanic(st, "called `Option::unwrap()` on a `None` value (empty sequence; simple/mod.rs:103)")
     if st == _ffi.ERR_CODE_OUT_OF_RANGE:
@@ -95,3 +97,22 @@ def align_pair(semantics, query, target, del_, ext, matrix, heuristics_present=F
                             H.ctypes.data if want_h else None)
     raise_for_status(st, "aln_align_pair")
     return res, qa[:res.aln_len].copy(), ta[:res.aln_len].copy(), D, H
+
+
+def align_pwm(seq, del_, ext, pwm, heuristics_present=False, want_directions=False, want_h=False, device=None, **kw):
+    """One blocking PWMAligner::perform_alignment through aln_align_pair (ALN_PWM_LOCAL).
+    Returns (PairResult, numbered u32[], residues u8[], D|None, H|None)."""
+    lib = _ffi.load()
+    t = np.ascontiguousarray(seq, dtype=np.uint8)
+    p, keep = make_params(_ffi.PWM_LOCAL, del_, ext, pwm, heuristics_present, **kw)
+    W, M = keep.shape[1], len(t)
+    res = _ffi.PairResult()
+    numbered = np.zeros(W + M + 2, dtype=np.uint32)
+    qal = np.zeros(W + M + 2, dtype=np.uint8)
+    D = np.zeros((M + 1, W + 1), dtype=np.uint8) if want_directions else None
+    H = np.zeros((M + 1, W + 1), dtype=np.float64) if want_h else None
+    st = lib.aln_align_pair(context(device), C.byref(p), None, W, t.ctypes.data, M, C.byref(res),
+                            numbered.ctypes.data, qal.ctypes.data, D.ctypes.data if want_directions else None,
+                            H.ctypes.data if want_h else None)
+    raise_for_status(st, "aln_align_pair")
+    return res, numbered[:res.aln_len].copy(), qal[:res.aln_len].copy(), D, H

@@ -29,7 +29,11 @@ enum aln_semantics {
     ALN_CORE_GLOBAL = 0,   /* SimpleGlobalAligner::perform_alignment   simple/mod.rs:42-145  */
     ALN_CORE_LOCAL = 1,    /* SimpleLocalAligner::perform_alignment    simple/mod.rs:168-264 */
     ALN_LEGACY_GLOBAL = 2, /* SimpleAligner::global_alignment          src/align/aligner_core.rs:96-183  */
-    ALN_LEGACY_LOCAL = 3   /* SimpleAligner::local_alignment           src/align/aligner_core.rs:185-269 */
+    ALN_LEGACY_LOCAL = 3,  /* SimpleAligner::local_alignment           src/align/aligner_core.rs:185-269 */
+    ALN_PWM_LOCAL = 4      /* PWMAligner::perform_alignment            aligner-core/src/pwm/mod.rs:29-126:
+                            * `target` = the aligner's query (rows), matrix = 4 x W position-weight matrix whose column x scores
+                            * PWM position x; `query` is ignored (N = W).  Aligned output: q_aln holds uint32_t PWM column
+                            * numbers (0 = gap; capacity N+M+2 entries, 4-byte aligned), t_aln the residue codes / blank. */
 };
 
 /* Status codes.  1 mirrors `Err(Error::UnnecessaryArgument)` (lib.rs:51; simple/mod.rs:49-51,175-177).
@@ -43,7 +47,8 @@ enum aln_status {
     ALN_ERR_DEVICE = 5,              /* HIP runtime / kernel failure (aln_last_error() has the text)      */
     ALN_ERR_OOM = 6,
     ALN_ERR_INVALID_ARGUMENT = 7,
-    ALN_ERR_UNSUPPORTED = 8
+    ALN_ERR_UNSUPPORTED = 8,
+    ALN_ERR_MATRIX_SHAPE = 9         /* Err(Error::MatrixShapeError): PWM without exactly 4 rows, pwm/mod.rs:40-42 */
 };
 
 /* What the caller wants back (bitmask in aln_params.outputs). */
@@ -101,7 +106,9 @@ int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint8_t *query,
 
 /* ---- batch driver: semantics == map of aln_align_pair over independent pairs (the reference's only batch site is
  * statistics/mod.rs:255-286).  Pair i: query = seqs[q_off[i] .. +q_len[i]), target = seqs[t_off[i] .. +t_len[i]).
- * tb_buf (optional): pair i's aligned query at tb_off[i], aligned target at tb_off[i] + q_len[i] + t_len[i] + 2. ---- */
+ * tb_buf (optional): pair i's aligned query at tb_off[i], aligned target at tb_off[i] + q_len[i] + t_len[i] + 2.
+ * ALN_PWM_LOCAL: q_len[i] is ignored (N = matrix cols); tb_off[i] must be a multiple of 4; pair i's uint32 column numbers
+ * start at tb_off[i], its residue string at tb_off[i] + 4 * (cols + t_len[i] + 2). ---- */
 int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
                     const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
                     aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off);

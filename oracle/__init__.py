@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 
 TOP, LEFT, DIAGONAL, BEGINNING = 0, 1, 2, 3
-CORE_GLOBAL, CORE_LOCAL, LEGACY_GLOBAL, LEGACY_LOCAL = 0, 1, 2, 3
+CORE_GLOBAL, CORE_LOCAL, LEGACY_GLOBAL, LEGACY_LOCAL, PWM_LOCAL = 0, 1, 2, 3, 4
+ERR_MATRIX_SHAPE = 9
 OK, ERR_UNNECESSARY_ARGUMENT, ERR_EMPTY_SEQUENCE, ERR_CODE_OUT_OF_RANGE, ERR_NO_POSITIVE_CELL = 0, 1, 2, 3, 4
 
 
@@ -74,6 +75,30 @@ def align(semantics, q, t, del_, ext, matrix, want_matrices=False, heuristics_pr
                coords=((res.coords[0], res.coords[1]), (res.coords[2], res.coords[3])),
                end=(res.end_y, res.end_x), start=(res.start_y, res.start_x),
                qa=qa[:res.aln_len].copy(), ta=ta[:res.aln_len].copy())
+    if want_matrices:
+        out["H"], out["D"] = H, D
+    return out
+
+
+def align_pwm(seq, del_, ext, pwm, want_matrices=False, heuristics_present=False, blank=98):
+    """PWMAligner::perform_alignment.  Returns dict(status, f, coords, end, start, numbered, qal[, H, D])."""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    Q = len(seq)
+    p, keep = _params(PWM_LOCAL, del_, ext, pwm, heuristics_present, blank)
+    Wd = keep.shape[1]
+    res = Result()
+    numbered = np.zeros(Q + Wd + 2, dtype=np.uint32)
+    qal = np.zeros(Q + Wd + 2, dtype=np.uint8)
+    H = np.zeros((Q + 1, Wd + 1), dtype=np.float64) if want_matrices else None
+    D = np.zeros((Q + 1, Wd + 1), dtype=np.uint8) if want_matrices else None
+    lib().orc_align_pwm(C.byref(p), seq.ctypes.data_as(C.c_void_p), C.c_size_t(Q), C.byref(res),
+                        numbered.ctypes.data_as(C.c_void_p), qal.ctypes.data_as(C.c_void_p),
+                        H.ctypes.data_as(C.c_void_p) if want_matrices else None,
+                        D.ctypes.data_as(C.c_void_p) if want_matrices else None)
+    out = dict(status=res.status, f=res.f, score=res.score,
+               coords=((res.coords[0], res.coords[1]), (res.coords[2], res.coords[3])),
+               end=(res.end_y, res.end_x), start=(res.start_y, res.start_x),
+               numbered=numbered[:res.aln_len].copy(), qal=qal[:res.aln_len].copy())
     if want_matrices:
         out["H"], out["D"] = H, D
     return out

@@ -13,6 +13,7 @@
  *   LEGACY_GLOBAL src/align/aligner_core.rs:96-183        (SimpleAligner::global_alignment, i32)
  *   LEGACY_LOCAL  src/align/aligner_core.rs:185-269       (SimpleAligner::local_alignment, i32)
  *   midline/freq  aligner-core/src/alignment.rs:12-43
+ *   PWM_LOCAL     aligner-core/src/pwm/mod.rs:29-126     (PWMAligner::perform_alignment)
  * Third-party arithmetic not in the reference tree: ndarray-stats 0.5.0 (Cargo.lock:1291)
  * QuantileExt::argmax / ::max, used at simple/mod.rs:212,247 -- restated as "first maximum in
  * logical row-major order, replace only on strictly greater" (published behaviour of 0.5.0).
@@ -232,6 +233,65 @@ int orc_align(const orc_params *p, const uint8_t *q, size_t N, const uint8_t *t,
         free(H); free(D);
         return res->status = ORC_OK;
     }
+}
+
+/* pwm/mod.rs:29-126 */
+int orc_align_pwm(const orc_params *p, const uint8_t *seq, size_t Q, orc_result *res, uint32_t *numbered, uint8_t *qal,
+                  double *H_out, uint8_t *D_out)
+{
+    memset(res, 0, sizeof(*res));
+    if (p->heuristics_present) return res->status = ORC_ERR_UNNECESSARY_ARGUMENT;   /* :36-38 */
+    if (p->rows != 4) return res->status = ORC_ERR_MATRIX_SHAPE;                    /* :40-42 */
+    for (size_t i = 0; i < Q; i++) if (seq[i] >= p->rows) return res->status = ORC_ERR_CODE_OUT_OF_RANGE;
+    const size_t Wd = p->cols;            /* numbered_sequence = 1..=W */
+    const size_t W = Wd + 1, Hh = Q + 1;  /* dim = (Q+1, W+1) */
+    const double *S = p->matrix;
+    const int64_t rs = p->row_stride;
+    const double del = p->del, ext = p->ext;
+    double *H = (double *)calloc(Hh * W, sizeof(double));
+    uint8_t *D = (uint8_t *)malloc(Hh * W);
+    if (!H || !D) { free(H); free(D); return res->status = ORC_ERR_OOM; }
+    memset(D, ORC_BEGINNING, Hh * W);
+    double penalty = del;                 /* :50 */
+    for (size_t x = 1; x <= Wd; x++) {    /* :52 columns outer */
+        for (size_t y = 1; y <= Q; y++) { /* :53 query inner */
+            double v;
+            const double top = H[(y - 1) * W + x] - penalty;
+            const double left = H[y * W + x - 1] - penalty;
+            const double diag = H[(y - 1) * W + x - 1] + S[(int64_t)seq[y - 1] * rs + (int64_t)(x - 1)];
+            const uint8_t d = pick_b(top, left, diag, &v);
+            penalty = (d != ORC_BEGINNING) ? ext : del;
+            H[y * W + x] = v;
+            D[y * W + x] = d;
+        }
+    }
+    size_t best = 0;                      /* :76 argmax, first maximum in row-major order */
+    for (size_t i = 1; i < Hh * W; i++) if (H[i] > H[best]) best = i;
+    const size_t my = best / W, mx = best % W;
+    size_t cy = my, cx = mx, len = 0;
+    for (;;) {                            /* :81-103, no seed pair */
+        const uint8_t d = D[cy * W + cx];
+        if (d == ORC_BEGINNING) break;
+        if (d == ORC_TOP) { numbered[len] = 0; qal[len] = seq[cy - 1]; cy--; }
+        else if (d == ORC_LEFT) { numbered[len] = (uint32_t)cx; qal[len] = p->blank_code; cx--; }
+        else { numbered[len] = (uint32_t)cx; qal[len] = seq[cy - 1]; cx--; cy--; }
+        len++;
+    }
+    for (size_t i = 0, j = len ? len - 1 : 0; i < j; i++, j--) {
+        uint32_t a = numbered[i]; numbered[i] = numbered[j]; numbered[j] = a;
+        uint8_t b = qal[i]; qal[i] = qal[j]; qal[j] = b;
+    }
+    double f = H[0];                      /* :108 */
+    for (size_t i = 1; i < Hh * W; i++) if (H[i] > f) f = H[i];
+    res->f = f; res->score = f;
+    res->end_y = (uint32_t)my; res->end_x = (uint32_t)mx;
+    res->start_y = (uint32_t)cy; res->start_x = (uint32_t)cx;
+    res->coords[0] = cx + 1; res->coords[1] = mx + 1; res->coords[2] = cy + 1; res->coords[3] = my + 1;   /* :118-121 */
+    res->aln_len = (uint32_t)len;
+    if (H_out) memcpy(H_out, H, Hh * W * sizeof(double));
+    if (D_out) memcpy(D_out, D, Hh * W);
+    free(H); free(D);
+    return res->status = ORC_OK;
 }
 
 /* alignment.rs:25-42 */

@@ -9,14 +9,15 @@ extern "C" {
 
 /* aligner-core/src/enums.rs:9-15 discriminants */
 enum { ORC_TOP = 0, ORC_LEFT = 1, ORC_DIAGONAL = 2, ORC_BEGINNING = 3 };
-enum { ORC_CORE_GLOBAL = 0, ORC_CORE_LOCAL = 1, ORC_LEGACY_GLOBAL = 2, ORC_LEGACY_LOCAL = 3 };
+enum { ORC_CORE_GLOBAL = 0, ORC_CORE_LOCAL = 1, ORC_LEGACY_GLOBAL = 2, ORC_LEGACY_LOCAL = 3, ORC_PWM_LOCAL = 4 };
 enum {
     ORC_OK = 0,
     ORC_ERR_UNNECESSARY_ARGUMENT = 1, /* Error::UnnecessaryArgument, lib.rs:51 */
     ORC_ERR_EMPTY_SEQUENCE = 2,       /* reference panics */
     ORC_ERR_CODE_OUT_OF_RANGE = 3,    /* reference panics (ndarray OOB) */
     ORC_ERR_NO_POSITIVE_CELL = 4,     /* reference panics (argmax on a border) */
-    ORC_ERR_OOM = 6
+    ORC_ERR_OOM = 6,
+    ORC_ERR_MATRIX_SHAPE = 9         /* Error::MatrixShapeError, pwm/mod.rs:40-42 */
 };
 
 typedef struct {
@@ -38,6 +39,12 @@ typedef struct {
     uint32_t aln_len;
     int32_t status;
 } orc_result;
+
+/* PWMAligner::perform_alignment (aligner-core/src/pwm/mod.rs:29-126): seq = the aligner's `query` (rows, length Q),
+ * matrix = 4 x W position-weight matrix (columns 1..W).  numbered[i] = PWM column or 0 (capacity Q+W+2),
+ * qal[i] = residue code or blank.  res->coords as Alignment.coords; no seed pair, no panic on an empty result. */
+int orc_align_pwm(const orc_params *p, const uint8_t *seq, size_t Q, orc_result *res, uint32_t *numbered, uint8_t *qal,
+                  double *H_out, uint8_t *D_out);
 
 /* qa / ta: caller buffers of capacity M+N+2 each. H_out ((M+1)*(N+1) doubles) and D_out (bytes) optional. */
 int orc_align(const orc_params *p, const uint8_t *q, size_t N, const uint8_t *t, size_t M,

@@ -100,3 +100,33 @@ def legacy(q, t, dele, S, local):
     qa, ta = [q[mxx]], [t[myy]]
     _walk(Dm, q, t, myy, mxx, qa, ta)
     return dict(H=H, D=Dm, qa=qa[::-1], ta=ta[::-1], score=mf, end=(myy + 1, mxx + 1))
+
+
+def pwm(seq, dele, ext, M):
+    """PWMAligner::perform_alignment (pwm/mod.rs:29-126), independent restatement: M is a 4 x W nested list."""
+    Q, W = len(seq), len(M[0])
+    H = {(y, x): 0.0 for y in range(Q + 1) for x in range(W + 1)}
+    Dm = {k: B for k in H}
+    p = dele
+    for x in range(1, W + 1):
+        for y in range(1, Q + 1):
+            v, d = _pick(H[(y - 1, x)] - p, H[(y, x - 1)] - p, H[(y - 1, x - 1)] + M[seq[y - 1]][x - 1], True)
+            p = ext if d != B else dele
+            H[(y, x)] = v; Dm[(y, x)] = d
+    best = (0, 0)
+    for y in range(Q + 1):
+        for x in range(W + 1):
+            if H[(y, x)] > H[best]:
+                best = (y, x)
+    cy, cx = best
+    numbered, qal = [], []
+    while Dm[(cy, cx)] != B:
+        d = Dm[(cy, cx)]
+        if d == T:
+            numbered.append(0); qal.append(seq[cy - 1]); cy -= 1
+        elif d == L:
+            numbered.append(cx); qal.append(98); cx -= 1
+        else:
+            numbered.append(cx); qal.append(seq[cy - 1]); cx -= 1; cy -= 1
+    return dict(H=H, D=Dm, numbered=numbered[::-1], qal=qal[::-1], f=max(H.values()),
+                coords=((cx + 1, best[1] + 1), (cy + 1, best[0] + 1)))

@@ -349,3 +349,67 @@ def test_cli_on_reference_example(orc, blosum62, capsys, tmp_path):
     assert capsys.readouterr().out.strip() == "[Blank, A, W, Blank, H, E, Blank, E, E]"
     assert cli.main(["-i", book, "-g"]) == 0
     assert capsys.readouterr().out.strip() == "[Blank, Blank, A, Blank, Blank, W, Blank, H, E, Blank, E, E]"
+
+
+# ---------------------------------------------------------------- PWM aligner
+def _check_pwm(orc, seq, dele, ext, pwm, full=True, **kw):
+    from aligner_amd.pwm import PWMAligner
+    ref = orc.align_pwm(seq, dele, ext, pwm, want_matrices=full)
+    r = PWMAligner.from_seqs(seq).perform_alignment(dele, ext, pwm, want_matrices=full, **kw)
+    a = r.alignment
+    assert a.f == ref["f"] and a.coords == ref["coords"], (a.f, ref["f"], a.coords, ref["coords"])
+    assert a.numbered.tolist() == ref["numbered"].tolist() and a.query.tolist() == ref["qal"].tolist()
+    if full:
+        assert (r.alignment_matrix == ref["H"]).all() and (r.direction_matrix == ref["D"]).all()
+    return r
+
+
+@pytest.mark.parametrize("shape", [(40, 30), (330, 300), (700, 300), (64, 1), (5, 600)])
+def test_pwm_aligner_matches_oracle(orc, shape):
+    """PWMAligner::perform_alignment (pwm/mod.rs:29-126): random -1/0/1 PWMs (lib.rs:92-96) and a planted motif."""
+    Q, W = shape
+    rng = np.random.default_rng(Q * 7 + W)
+    pwm = rng.integers(-1, 2, (4, W)).astype(np.float64)
+    seq = rng.integers(0, 4, Q).astype(np.uint8)
+    for dele, ext in ((3, 1), (2, 2), (1, 2)):
+        _check_pwm(orc, seq, dele, ext, pwm)                       # generic kernels (H dump)
+        _check_pwm(orc, seq, dele, ext, pwm, full=False)           # fast kernels (v_perm byte select)
+    motif = rng.integers(0, 4, W).astype(np.uint8)
+    pwm2 = -np.ones((4, W)); pwm2[motif, np.arange(W)] = 2.0
+    if Q > W + 10:
+        seq2 = seq.copy(); seq2[5:5 + W] = motif
+        r = _check_pwm(orc, seq2, 3, 1, pwm2, full=False)
+        assert r.alignment.f == 2.0 * W
+    # real-valued PWM -> f64 kernels
+    _check_pwm(orc, seq, 1.5, 0.4, np.round(rng.normal(0, 1, (4, W)), 2), full=False)
+
+
+def test_pwm_errors_and_empty_result(orc):
+    from aligner_amd.pwm import PWMAligner
+    seq = np.array([0, 1, 2, 3, 0, 1], np.uint8)
+    with pytest.raises(AlignerError) as e:
+        PWMAligner.from_seqs(seq).perform_alignment(3, 1, np.zeros((3, 5)))
+    assert e.value.kind == ErrorKind.MatrixShapeError
+    with pytest.raises(AlignerError) as e:
+        PWMAligner.from_seqs(seq).perform_alignment(3, 1, np.zeros((4, 5)), Heuristics(1, 1, np.ones(4)))
+    assert e.value.kind == ErrorKind.UnnecessaryArgument
+    r = PWMAligner.from_seqs(seq).perform_alignment(3, 1, -np.ones((4, 5)))       # no positive cell: empty, no panic
+    assert r.alignment.f == 0.0 and len(r.alignment.numbered) == 0 and r.alignment.coords == ((1, 1), (1, 1))
+    ref = orc.align_pwm(seq, 3, 1, -np.ones((4, 5)))
+    assert ref["f"] == 0.0 and ref["coords"] == ((1, 1), (1, 1))
+
+
+def test_pwm_window_batch(orc):
+    """latent-repeat-search's inner loop as one batch: 400 windows of 330 nt against one 300-column PWM."""
+    from aligner_amd.pwm import align_windows
+    rng = np.random.default_rng(99)
+    pwm = rng.integers(-1, 2, (4, 300)).astype(np.float64)
+    chrom = rng.integers(0, 4, 20000).astype(np.uint8)
+    wins = [chrom[i * 45:i * 45 + 330] for i in range(400)]
+    res, alns = align_windows(wins, 3, 1, pwm)
+    for i in range(0, 400, 7):
+        ref = orc.align_pwm(wins[i], 3, 1, pwm)
+        assert res["f"][i] == ref["f"] and alns[i].coords == ref["coords"]
+        assert alns[i].numbered.tolist() == ref["numbered"].tolist() and alns[i].query.tolist() == ref["qal"].tolist()
+        fm = alns[i].get_frequency_matrix()
+        assert fm.shape == (4, 300) and fm.sum() == ((ref["numbered"] != 0) & (ref["qal"] != 98)).sum()

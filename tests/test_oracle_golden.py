@@ -129,3 +129,21 @@ def test_oracle_batch_threads_equal_single(orc, blosum62):
         one = orc.align(orc.CORE_LOCAL, b.query(i), b.target(i), 11, 2, blosum62)
         assert (r1[i].f, r1[i].aln_len, r1[i].status) == (one["f"], len(one["qa"]), one["status"])
         assert (r4[i].f, r4[i].aln_len) == (r1[i].f, r1[i].aln_len)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_pwm_matches_python_restatement(orc, seed):
+    """PWMAligner (pwm/mod.rs:29-126) has no reference test: parity unpinned beyond source reading; the C oracle and an
+    independent Python restatement must at least agree."""
+    rng = np.random.default_rng(100 + seed)
+    Q, W = int(rng.integers(1, 45)), int(rng.integers(1, 40))
+    seq = rng.integers(0, 4, Q).astype(np.uint8)
+    M = rng.integers(-1, 2, (4, W)).astype(np.float64) if seed % 2 == 0 else np.round(rng.normal(0, 1, (4, W)), 2)
+    dele, ext = [(3, 1), (1, 2), (2, 2)][seed % 3]
+    ref = pyref.pwm(seq.tolist(), float(dele), float(ext), M.tolist())
+    got = orc.align_pwm(seq, dele, ext, M, want_matrices=True)
+    assert (got["H"] == _H(ref["H"], Q, W)).all() and (got["D"] == _H(ref["D"], Q, W)).all()
+    assert got["numbered"].tolist() == ref["numbered"] and got["qal"].tolist() == ref["qal"]
+    assert got["f"] == ref["f"] and got["coords"] == ref["coords"]
+    assert orc.align_pwm(seq, dele, ext, M[:3])["status"] == orc.ERR_MATRIX_SHAPE
+    assert orc.align_pwm(seq, dele, ext, M, heuristics_present=True)["status"] == orc.ERR_UNNECESSARY_ARGUMENT
