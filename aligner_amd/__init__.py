@@ -10,6 +10,7 @@ from .alignment import Alignment, AlignmentResult
 from .batch import BatchResult, PairBatch, StagedBatch, align_batch
 from .enums import DNA, Direction, Protein
 from .errors import AlignerError, DeviceError, ErrorKind, ReferencePanic
+from .heuristic import HeuristicAligner, HeuristicPWMAligner, get_threshold, transform_matrix
 from .legacy import SimpleAligner
 from .matrices import get_blosum62, nucleotide_matrix
 from .pwm import PWMAligner, PWMAlignment, align_windows
@@ -19,4 +20,5 @@ __all__ = [
     "Alignment", "AlignmentResult", "BatchResult", "PairBatch", "StagedBatch", "align_batch", "DNA", "Direction",
     "Protein", "AlignerError", "DeviceError", "ErrorKind", "ReferencePanic", "SimpleAligner", "get_blosum62",
     "nucleotide_matrix", "PWMAligner", "PWMAlignment", "align_windows", "Heuristics", "SimpleGlobalAligner", "SimpleLocalAligner",
+    "HeuristicAligner", "HeuristicPWMAligner", "get_threshold", "transform_matrix",
 ]

@@ -413,3 +413,73 @@ def test_pwm_window_batch(orc):
         assert alns[i].numbered.tolist() == ref["numbered"].tolist() and alns[i].query.tolist() == ref["qal"].tolist()
         fm = alns[i].get_frequency_matrix()
         assert fm.shape == (4, 300) and fm.sum() == ((ref["numbered"] != 0) & (ref["qal"] != 98)).sum()
+
+
+# ---------------------------------------------------------------- heuristic re-estimation loop
+def test_heuristic_aligner_loop_matches_oracle_loop(orc, blosum62):
+    """HeuristicAligner (heuristic/mod.rs:36-78): every iteration is a core-local alignment with a real-valued matrix
+    (f64 kernels).  The same loop driven by the CPU oracle must visit the same matrices and end on the same result."""
+    from aligner_amd.alignment import Alignment
+    from aligner_amd.heuristic import HeuristicAligner, transform_matrix
+    rng = np.random.default_rng(31)
+    q = rng.integers(0, 20, 160).astype(np.uint8)
+    t = np.concatenate([rng.integers(0, 20, 30).astype(np.uint8), q[40:130], rng.integers(0, 20, 25).astype(np.uint8)])
+    freqs = np.bincount(t, minlength=24).astype(np.float64) / len(t)
+    h = Heuristics(kd=-0.5, r_squared=0.0, frequencies=freqs)
+    got = HeuristicAligner.from_seqs(q, t, Protein).perform_alignment(11.0, 2.0, blosum62, h)
+    # oracle-driven replay of the loop
+    r2 = float(blosum62.shape[0] * blosum62.shape[1])
+    m = transform_matrix(blosum62, h.kd, r2, freqs)
+    max_f, iters = 0.0, 0
+    while True:
+        ref = orc.align(orc.CORE_LOCAL, q, t, 11.0, 2.0, m)
+        assert ref["status"] == 0
+        iters += 1
+        if ref["f"] > max_f:
+            max_f = ref["f"]
+            m = transform_matrix(Alignment(Protein, ref["qa"], ref["ta"], ref["coords"], ref["f"]).get_frequency_matrix(),
+                                 h.kd, r2, freqs)
+        else:
+            break
+    assert iters >= 2
+    assert got.alignment.f == ref["f"] and got.alignment.coords == ref["coords"]
+    assert got.alignment.query.tolist() == ref["qa"].tolist() and got.alignment.target.tolist() == ref["ta"].tolist()
+    assert (got.matrix == m).all()
+    with pytest.raises(AlignerError) as e:
+        HeuristicAligner.from_seqs(q, t, Protein).perform_alignment(11.0, 2.0, blosum62, None)
+    assert e.value.kind == ErrorKind.MissingArgument
+
+
+def test_heuristic_pwm_aligner_loop_matches_oracle_loop(orc):
+    """HeuristicPWMAligner (heuristic/mod.rs:104-140): the same loop around PWMAligner, frequency matrix 4 x W."""
+    from aligner_amd.enums import DNA
+    from aligner_amd.heuristic import HeuristicPWMAligner, transform_matrix
+    from aligner_amd.pwm import PWMAlignment
+    rng = np.random.default_rng(77)
+    W = 60
+    unit = rng.integers(0, 4, W).astype(np.uint8)
+    seq = np.concatenate([rng.integers(0, 4, 40).astype(np.uint8)] +
+                         [np.where(rng.random(W) < 0.15, rng.integers(0, 4, W), unit).astype(np.uint8) for _ in range(3)])
+    freqs = np.bincount(seq, minlength=4).astype(np.float64) / len(seq)
+    start = rng.normal(0, 1, (4, W))
+    h = Heuristics(kd=-0.3, r_squared=float(4 * W), frequencies=freqs)
+    got = HeuristicPWMAligner.from_seqs(seq, None, DNA).perform_alignment(4.0, 1.0, start, h)
+    m = transform_matrix(start, h.kd, h.r_squared, freqs)
+    max_f, iters = 0.0, 0
+    while True:
+        ref = orc.align_pwm(seq, 4.0, 1.0, m)
+        assert ref["status"] == 0
+        iters += 1
+        if ref["f"] > max_f:
+            max_f = ref["f"]
+            m = transform_matrix(PWMAlignment(DNA, ref["numbered"], ref["qal"], W, ref["coords"], ref["f"])
+                                 .get_frequency_matrix(), h.kd, h.r_squared, freqs)
+        else:
+            break
+    assert iters >= 2
+    assert got.alignment.f == ref["f"] and got.alignment.coords == ref["coords"]
+    assert got.alignment.numbered.tolist() == ref["numbered"].tolist() and got.alignment.query.tolist() == ref["qal"].tolist()
+    assert (got.matrix == m).all()
+    with pytest.raises(AlignerError) as e:
+        HeuristicPWMAligner.from_seqs(seq, None, DNA).perform_alignment(4.0, 1.0, start, None)
+    assert e.value.kind == ErrorKind.MissingArgument

@@ -138,3 +138,18 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
                 assert "aligner_oracle" not in src, f
+
+
+def test_transform_matrix_properties(blosum62):
+    """aligner-helpers/src/matrices/mod.rs:19-68: the transformed matrix has expectation k_d under p and norm^2 r^2."""
+    from aligner_amd.heuristic import find_roots_quadratic, get_threshold, transform_matrix
+    freqs = np.full(24, 1 / 24.0)
+    kd, r2 = -0.5, 576.0
+    m = transform_matrix(blosum62, kd, r2, freqs)
+    p = np.outer(freqs, np.full(24, 1 / 24.0))
+    assert abs((p * m).sum() - kd) < 1e-9 and abs((m * m).sum() - r2) < 1e-6
+    assert find_roots_quadratic(1.0, -3.0, 2.0) == (1.0, 2.0) and find_roots_quadratic(1.0, 2.0, 1.0) == (-1.0,)
+    assert find_roots_quadratic(1.0, 0.0, 1.0) == () and get_threshold(24) == 24.6 and get_threshold(7) == 0.0
+    with pytest.raises(Exception) as e:        # |k_d| > sqrt(r^2 * sum p^2): no real root -> Err(WrongMatrixSpecified)
+        transform_matrix(blosum62, -1.5, r2, freqs)
+    assert type(e.value).__name__ == "WrongMatrixSpecified"
