@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libaligner_hip.so")
 SOURCES = ["aln_kernels.hip", "aln_host.hip"]
-HEADERS = ["aln_device.h", os.path.join("..", "..", "include", "aligner_hip.h")]
+HEADERS = ["aln_device.h", "aln_fast.cuh", os.path.join("..", "..", "include", "aligner_hip.h")]
 # -ffp-contract=off: the f64 kernels must be the reference's add/sub/max/compare, never an fma
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]

@@ -94,6 +94,98 @@ __device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
+// ---- single-pair kernel, steady state of the core-local fill: ONE asm statement per step.  A lone wave issues one
+// instruction per ~4-5 cycles whatever its kind (VALU, SALU, LDS, s_nop), so the step is written by hand to the minimum
+// instruction count, with every gfx950 hazard slot (VALU writes VCC -> VALU reads it: 2 wait states; VALU write -> DPP
+// read: 2) filled by useful work:
+//   top-in   lanes 0..3 <- the boundary group G rotated by (k & 15) (row_ror; only lane 0 matters), then lanes 1..63 <-
+//            lane-1's bottom cell (wave_shr:1)
+//   LDS      query offset of step k+2, profile bytes of step k+1 (both complete before the statement ends)
+//   per cell penalty select, three candidate keys, v_max3, T form, Beginning tag, direction bits, end-cell tracker
+//   bottom   cell -> 64-deep lane shift register towards lane 63's publisher (wave_shl:1)
+// `two` is 2 in every lane except lane 0 of strip 0, which holds an impossible T: row 1's carried penalty comes from the
+// advice (not from the border above), and this path only runs over column groups whose advice bits are all zero.
+#define ALN_S_HEAD(ROR, PWREAD)                                                                                \
+    "v_mov_b32_dpp %[tin], %[G] " ROR " row_mask:0x1 bank_mask:0x1\n\t"                                      \
+    "v_mov_b32_dpp %[tin], %[TL] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                  \
+    "v_cmp_eq_u32 vcc, %[two], %[tin]\n\t"                                                                    \
+    "ds_read_u16 %[qvn], %[qop] offset:%[qoff]\n\t"                                                          \
+    "v_add_u32 %[la], %[prow], %[qvc]\n\t"                                                                   \
+    PWREAD " %[pwn], %[la]\n\t"
+#define ALN_S_TAIL                                                                                             \
+    "v_mov_b32_dpp %[on], %[oo] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                    \
+    "s_waitcnt lgkmcnt(0)"
+#define ALN_S_BODY1                                                                                            \
+    "v_add_u32_sdwa %[c0], %[hd], sext(%[pwc]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+    "v_cndmask_b32 %[np], %[ne], %[nd], vcc\n\t"                                                              \
+    "v_add_u32 %[ta], %[tin], %[np]\n\t"                                                                      \
+    "v_add3_u32 %[tb], %[TL], %[np], -1\n\t"                                                                  \
+    "v_max3_i32 %[k0], %[ta], %[tb], %[c0]\n\t"                                                               \
+    "v_and_or_b32 %[TL], %[k0], -4, 2\n\t"                                                                    \
+    "v_max_u32 %[k0], %[k0], 3\n\t"                                                                           \
+    "v_mov_b32 %[on], %[TL]\n\t"                                                                           \
+    "v_lshl_add_u32 %[p0], %[TL], 11, %[kt]\n\t"                                                              \
+    "v_alignbit_b32 %[dw], %[k0], %[dw], 2\n\t"                                                               \
+    "v_max_i32 %[r0], %[r0], %[p0]\n\t"
+// R = 2: row 1's diagonal is row 0's previous cell, its top is row 0's new cell
+#define ALN_S_BODY2                                                                                            \
+    "v_add_u32_sdwa %[c0], %[hd], sext(%[pwc]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
+    "v_add_u32_sdwa %[c1], %[T0], sext(%[pwc]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
+    "v_cndmask_b32 %[np], %[ne], %[nd], vcc\n\t"                                                              \
+    "v_add_u32 %[ta], %[tin], %[np]\n\t"                                                                      \
+    "v_add3_u32 %[tb], %[T0], %[np], -1\n\t"                                                                  \
+    "v_max3_i32 %[k0], %[ta], %[tb], %[c0]\n\t"                                                               \
+    "v_cmp_gt_u32 vcc, 3, %[k0]\n\t"                                                                          \
+    "v_and_or_b32 %[T0], %[k0], -4, 2\n\t"                                                                    \
+    "v_max_u32 %[k0], %[k0], 3\n\t"                                                                           \
+    "v_cndmask_b32 %[np], %[ne], %[nd], vcc\n\t"                                                              \
+    "v_add_u32 %[ta], %[T0], %[np]\n\t"                                                                       \
+    "v_add3_u32 %[tb], %[TL], %[np], -1\n\t"                                                                  \
+    "v_max3_i32 %[c1], %[ta], %[tb], %[c1]\n\t"                                                               \
+    "v_alignbit_b32 %[dw], %[k0], %[dw], 2\n\t"                                                               \
+    "v_and_or_b32 %[TL], %[c1], -4, 2\n\t"                                                                    \
+    "v_max_u32 %[c1], %[c1], 3\n\t"                                                                           \
+    "v_mov_b32 %[on], %[TL]\n\t"                                                                           \
+    "v_lshl_add_u32 %[p0], %[T0], 11, %[kt]\n\t"                                                              \
+    "v_alignbit_b32 %[dw], %[c1], %[dw], 2\n\t"                                                               \
+    "v_max_i32 %[r0], %[r0], %[p0]\n\t"                                                                       \
+    "v_lshl_add_u32 %[p0], %[TL], 11, %[kt]\n\t"                                                              \
+    "v_max_i32 %[r1], %[r1], %[p0]\n\t"
+
+// lane-local state of the asm step (all VGPRs) -- the same quantities FastStrip carries through its C++ step
+struct SingleRegs {
+    int T0, TL;               // this lane's cells of the previous column (T form); R = 1 uses TL only
+    int r0, r1;               // packed end-cell trackers
+    int hd;                   // diagonal of row 0: the cell that came in from above one step ago
+    uint32_t dw;              // direction bits
+    uint32_t pw, qv;          // profile bytes of this step / query offset of the next step's profile read
+    int outq;                 // publisher shift register
+};
+template <int R, int NR>
+__device__ __forceinline__ void single_step_asm(SingleRegs &s, int G, int two, uint32_t qop, uint32_t prow, int ne, int nd, int kt)
+{
+    int tin, np, ta, tb, c0, c1, k0, p0, on;
+    uint32_t qvn, pwn, la;
+#define ALN_S_OPERANDS                                                                                         \
+    : [tin] "=&v"(tin), [np] "=&v"(np), [ta] "=&v"(ta), [tb] "=&v"(tb), [c0] "=&v"(c0), [c1] "=&v"(c1),      \
+      [k0] "=&v"(k0), [p0] "=&v"(p0), [on] "=&v"(on), [qvn] "=&v"(qvn), [pwn] "=&v"(pwn), [la] "=&v"(la),     \
+      [T0] "+v"(s.T0), [TL] "+v"(s.TL), [r0] "+v"(s.r0), [r1] "+v"(s.r1), [dw] "+v"(s.dw)                     \
+    : [G] "v"(G), [two] "v"(two), [qop] "v"(qop), [prow] "v"(prow), [qvc] "v"(s.qv), [pwc] "v"(s.pw),         \
+      [hd] "v"(s.hd), [ne] "v"(ne), [nd] "v"(nd), [oo] "v"(s.outq), [kt] "s"(kt), [qoff] "n"(2 * NR + 4),      \
+      [nr] "n"(NR)                                                                                             \
+    : "vcc"
+    if constexpr (R == 1) {
+        if constexpr (NR == 0) asm volatile(ALN_S_HEAD("quad_perm:[0,1,2,3]", "ds_read_u8") ALN_S_BODY1 ALN_S_TAIL ALN_S_OPERANDS);
+        else asm volatile(ALN_S_HEAD("row_ror:%[nr]", "ds_read_u8") ALN_S_BODY1 ALN_S_TAIL ALN_S_OPERANDS);
+    } else {
+        if constexpr (NR == 0) asm volatile(ALN_S_HEAD("quad_perm:[0,1,2,3]", "ds_read_u16") ALN_S_BODY2 ALN_S_TAIL ALN_S_OPERANDS);
+        else asm volatile(ALN_S_HEAD("row_ror:%[nr]", "ds_read_u16") ALN_S_BODY2 ALN_S_TAIL ALN_S_OPERANDS);
+    }
+#undef ALN_S_OPERANDS
+    s.hd = tin; s.pw = pwn; s.qv = qvn; s.outq = on;
+}
+
 // Everything a strip needs that is uniform over the pair.  Passed BY VALUE so that it lives in (scalar) registers.
 struct FastIn {
     int lane;
@@ -162,6 +254,10 @@ struct FastStrip {
     int *bring;                // 2 x 64 T values of the row above this strip
     int qv, top0v;
     uint64_t gpre;             // prefetched granule of the next 16-column group (lanes 0..15)
+    // hand-written steady state (single-pair kernel, core local, R <= 2)
+    static constexpr bool ASMPATH = SINGLE && SEM == ALN_CORE_LOCAL && (R == 1 || R == 2);
+    int twov;                  // 2; lane 0 of strip 0: a value no cell takes (row 1's penalty never follows the border)
+    uint64_t advmask;          // strip 0: which of the 64 advice bytes in advchunk are set
 
     __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s)
         : in(i), strip(s), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
@@ -282,7 +378,7 @@ struct FastStrip {
                     if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 1) in.brow0[x] = bottom;
                 }
             }
-            if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) {
+            if (SEM == ALN_CORE_LOCAL && !SINGLE && zsel_on && (uint32_t)lane == lb) {
                 int hb = Tl[0];
 #pragma unroll
                 for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Tl[r];
@@ -330,9 +426,112 @@ struct FastStrip {
 
     // four blocks of SPB steps -> one 16-byte store per lane (1 KiB per wave, coalesced).  The block loop is a real
     // loop (not unrolled): unrolling 4*SPB steps makes the scheduler hoist every step's uniform values and spill.
+    // the single-pair kernel's bottom-row zero flags travel as the direction words of the lane that owns row M (tag 3 =
+    // Beginning <=> H == 0): one dword per block instead of one byte store per step
+    __device__ __forceinline__ void store_zdw(uint32_t block)
+    {
+        if (SINGLE && SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) reinterpret_cast<uint32_t *>(in.zrow)[block] = dw;
+    }
+
+    // 16 steady-state steps through the asm step (R = 1: one block, R = 2: two blocks), w0 / w1 = their direction words
+    template <int B>
+    __device__ __forceinline__ void asm_block(SingleRegs &sr, const int G, const uint32_t qop, const uint32_t prow32, const int kt0)
+    {
+        if constexpr (R == 1) {
+            single_step_asm<1, 0>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 0);
+            single_step_asm<1, 1>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 1);
+            single_step_asm<1, 2>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 2);
+            single_step_asm<1, 3>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 3);
+            single_step_asm<1, 4>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 4);
+            single_step_asm<1, 5>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 5);
+            single_step_asm<1, 6>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 6);
+            single_step_asm<1, 7>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 7);
+            single_step_asm<1, 8>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 8);
+            single_step_asm<1, 9>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 9);
+            single_step_asm<1, 10>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 10);
+            single_step_asm<1, 11>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 11);
+            single_step_asm<1, 12>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 12);
+            single_step_asm<1, 13>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 13);
+            single_step_asm<1, 14>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 14);
+            single_step_asm<1, 15>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 15);
+        } else {
+            single_step_asm<2, B + 0>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 0);
+            single_step_asm<2, B + 1>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 1);
+            single_step_asm<2, B + 2>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 2);
+            single_step_asm<2, B + 3>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 3);
+            single_step_asm<2, B + 4>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 4);
+            single_step_asm<2, B + 5>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 5);
+            single_step_asm<2, B + 6>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 6);
+            single_step_asm<2, B + 7>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 7);
+        }
+    }
+
+    // steady-state quad of the single-pair core-local kernel: 16-column units through the asm step; a unit of strip 0
+    // whose advice bits are not all zero takes the C++ step (rare: second and later passes only)
+    __device__ __forceinline__ void quad_asm(uint4 *dirq, const uint32_t kb)
+    {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const uint32_t prow32 = (uint32_t)(uintptr_t)prow;
+#pragma unroll 1
+        for (uint32_t u = 0; u < 4u / R; ++u) {
+            const uint32_t ku = (kb + u * R) * SPB;                     // first step of the unit, a multiple of 16
+            bool slow = false;
+            if (FIRST && in.hazard) {
+                if ((ku & 63u) == 0) {
+                    const uint32_t xi = ku + (uint32_t)lane;
+                    advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
+                    advmask = __ballot(advchunk != 0);
+                }
+                slow = ((advmask >> (ku & 63u)) & 0xffffull) != 0;
+            }
+            if (slow) {
+                if (!FIRST) top0v = bring[ku & 127u];
+#pragma unroll 1
+                for (uint32_t jj = 0; jj < (uint32_t)R; ++jj) {
+                    const uint32_t k0 = ku + jj * SPB;
+                    if (!FIRST && ((k0 + SPB) & 15u) == 0) stage_boundary16((k0 + SPB) >> 4);
+#pragma unroll
+                    for (int kk = 0; kk < SPB; ++kk) step<false>(k0 + kk);
+                    if (!LAST && ((k0 + SPB) & 15u) == 0) publish(k0 + SPB - 1);
+                    const uint32_t w = u * R + jj;
+                    if (w == 0) v.x = dw; else if (w == 1) v.y = dw; else if (w == 2) v.z = dw; else v.w = dw;
+                    store_zdw(kb + w);
+                }
+                continue;
+            }
+            // boundary cells of columns ku .. ku+15 in the order row_ror hands them to lane 0
+            int G = 2;
+            if (!FIRST) G = bring[(ku + ((16u - (uint32_t)lane) & 15u)) & 127u];
+            SingleRegs sr;
+            sr.T0 = Tl[0]; sr.TL = Tl[R - 1]; sr.r0 = rbv[0]; sr.r1 = rbv[R - 1]; sr.hd = hdiag; sr.dw = dw;
+            sr.pw = (uint32_t)pw; sr.qv = (uint32_t)qv; sr.outq = outq;
+            const uint32_t qop = (uint32_t)(uintptr_t)qo_lane + 2u * ku;
+            const int kt0 = (int)(2047u - (ku & 2047u));
+            if constexpr (R == 1) {
+                if (!FIRST) stage_boundary16((ku + 16u) >> 4);
+                asm_block<0>(sr, G, qop, prow32, kt0);
+                if (u == 0) v.x = sr.dw; else if (u == 1) v.y = sr.dw; else if (u == 2) v.z = sr.dw; else v.w = sr.dw;
+            } else {
+                asm_block<0>(sr, G, qop, prow32, kt0);
+                if (u == 0) v.x = sr.dw; else v.z = sr.dw;
+                if (zsel_on && (uint32_t)lane == lb) reinterpret_cast<uint32_t *>(in.zrow)[kb + 2 * u] = sr.dw;
+                if (!FIRST) stage_boundary16((ku + 16u) >> 4);
+                asm_block<8>(sr, G, qop, prow32, kt0);
+                if (u == 0) v.y = sr.dw; else v.w = sr.dw;
+            }
+            if (R > 1) { Tl[0] = sr.T0; rbv[R - 1] = sr.r1; }
+            Tl[R - 1] = sr.TL; rbv[0] = sr.r0; hdiag = sr.hd; dw = sr.dw;
+            pw = (PW)sr.pw; qv = (int)sr.qv; outq = sr.outq; bottom = sr.TL;
+            if (!LAST) publish(ku + 15u);
+            store_zdw(kb + u * R + (R - 1));
+        }
+        if (in.store_dirs) dirq[(size_t)(kb >> 2) * 64] = v;
+    }
+
     template <bool MASKED>
     __device__ __forceinline__ void quad(uint4 *dirq, const uint32_t kb)
     {
+        if constexpr (!MASKED && ASMPATH) { quad_asm(dirq, kb); return; }
         uint4 v = make_uint4(0, 0, 0, 0);
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; ++j) {
@@ -341,6 +540,7 @@ struct FastStrip {
 #pragma unroll
             for (int kk = 0; kk < SPB; ++kk) step<MASKED>(k0 + kk);
             if (SINGLE && !LAST && k0 + SPB >= 64u && ((k0 + SPB) & 15u) == 0) publish(k0 + SPB - 1);
+            store_zdw(kb + j);
             if (j == 0) v.x = dw;
             else if (j == 1) v.y = dw;
             else if (j == 2) v.z = dw;
@@ -428,6 +628,8 @@ struct FastStrip {
         hdiag = LOCAL || yb == 0 ? 2 : 2 + (int)yb * in.nd4;            // H[yb][0]; yb < M always for valid lanes
         bottom = Tl[R - 1];
         inchunk = 2; qchunk = 0; advchunk = 0; dw = 0; outq = 0; qv = 0; top0v = 2;
+        twov = (FIRST && lane == 0) ? 1 : 2;                 // T is always 2 (mod 4)
+        advmask = 0;
         if constexpr (SINGLE) {
             qo_lane = reinterpret_cast<const uint8_t *>(in.qo_pad + 63 - lane);
             bring = in.bring;
@@ -459,6 +661,7 @@ struct FastStrip {
             const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
             for (; kb < e0; kb += 4) quad<true>(dirq, kb);
             for (; kb < e1; kb += 4) quad<false>(dirq, kb);
+            if (ASMPATH && !FIRST) top0v = bring[(kb * SPB) & 127u];     // the C++ step reads its boundary cell one step ahead
             for (; kb < seg_end; kb += 4) quad<true>(dirq, kb);
             if (ckmode && kb < nkb && kb * SPB == next_ck) {
                 if (in.ck_mode == 1) checkpoint(slot, true);

@@ -41,6 +41,14 @@ struct aln_ctx {
     std::mutex mu;
 };
 
+// bytes of the single-pair kernel's advice array and of its bottom-row record (one direction dword per block of the last
+// strip, at most (N + 63) / 2 + 4 blocks at R = 8), equal sizes, 256-aligned
+static inline uint64_t single_advice_bytes(uint64_t N)
+{
+    const uint64_t a = N + 128, z = 4 * ((N + 63) / 2 + 8);
+    return ((a > z ? a : z) + 255) & ~255ull;
+}
+
 struct aln_batch {
     aln_ctx *ctx = nullptr;
     aln_params params{};
@@ -341,7 +349,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     if (want_h) BCHK(dmalloc((void **)&b->d_hmat, hm_total * sc_size));
     if (!b->single_pairs.empty()) {
         BCHK(dmalloc((void **)&b->d_granules, b->granule_bytes));
-        BCHK(dmalloc((void **)&b->d_advice1, 2ull * (b->single_max_n + 128)));
+        BCHK(dmalloc((void **)&b->d_advice1, 2ull * single_advice_bytes(b->single_max_n)));
         BCHK(dmalloc((void **)&b->d_cand, 16ull * (b->single_max_n + 64)));
         BCHK(dmalloc((void **)&b->d_ctrl, 256));
         BCHK(dmalloc((void **)&b->d_tbmap, b->tbmap_entries * 16));
@@ -430,7 +438,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         sa.seqs = b->d_seqs; sa.descs = b->d_descs; sa.pair = b->single_pairs[j]; sa.dirs = b->d_dirs;
         sa.results = b->d_results; sa.granules = b->d_granules;
         sa.gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
-        sa.advice = b->d_advice1; sa.zrow = b->d_advice1 + (b->single_max_n + 128);
+        sa.advice = b->d_advice1; sa.zrow = b->d_advice1 + single_advice_bytes(b->single_max_n);
         sa.cand = b->d_cand; sa.ctrl = b->d_ctrl; sa.matrix = b->d_matrix;
         sa.rows = b->params.rows; sa.cols = b->params.cols; sa.del = b->params.del; sa.ext = b->params.ext;
         sa.semantics = b->params.semantics; sa.R = b->single_r[j];
@@ -440,7 +448,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
         const uint32_t lds = (uint32_t)(((uint64_t)sa.rows * sa.cols * 4 + 15) & ~15ull) + ((sa.cols * 64u * sa.R + 15u) & ~15u) +
                              (((d.N + 192u) * 2u + 15u) & ~15u) + 512u;
-        aln_launch_single_init(&sa, d.N + 66, s);
+        aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), s);
         for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
             sa.pass = pass;
             HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 8, s));

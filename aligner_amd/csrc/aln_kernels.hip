@@ -668,11 +668,20 @@ __global__ __launch_bounds__(64) void aln_single_finalize_kernel(SingleArgs a)
     const int bv = o.bv;
     const uint32_t by = o.by, bx = o.bx;
     int mismatch = 0;
-    if (a.hazard) for (uint32_t x = 2 + lane; x <= N; x += 64) mismatch |= (a.advice[x] != a.zrow[x - 1]);
+    // H[M][x] == 0 <=> the stored tag of cell (M, x) is 3; the last strip recorded the direction words of the lane that
+    // owns row M, one per block
+    const uint32_t rows_last = M - (a.ns - 1) * 64u * a.R;
+    const uint32_t lb = (rows_last - 1) / a.R, rb = (rows_last - 1) % a.R, spb = 16u / a.R;
+    const uint32_t *zdw = reinterpret_cast<const uint32_t *>(a.zrow);
+    auto bottom_zero = [&](uint32_t x) -> uint8_t {                 // x = 1 .. N
+        const uint32_t k = x - 1 + lb;
+        return ((zdw[k / spb] >> aln_dir_bitpos(k, rb, lb, N, (int)a.R)) & 3u) == 3u ? 1 : 0;
+    };
+    if (a.hazard) for (uint32_t x = 2 + lane; x <= N; x += 64) mismatch |= (a.advice[x] != bottom_zero(x - 1));
     const bool again = __any(mismatch);
     const bool aborted = a.ctrl[0] != 0;
     if (again && !aborted) {
-        for (uint32_t x = 2 + lane; x <= N; x += 64) a.advice[x] = a.zrow[x - 1];
+        for (uint32_t x = 2 + lane; x <= N; x += 64) a.advice[x] = bottom_zero(x - 1);
         if (lane == 0) {
             if (a.pass + 1 < a.max_passes) a.ctrl[1 + a.pass + 1] = 1;
             else a.ctrl[15] = a.pass + 1;               // not self-consistent within the cap: strict-order kernel
