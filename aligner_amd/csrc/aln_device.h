@@ -78,7 +78,7 @@ struct SingleArgs {
     uint32_t pair;
     uint8_t *dirs;
     aln_pair_result *results;
-    uint64_t *granules;       // ns rows of gstride granules, zeroed before every pass
+    uint32_t *granules;       // ns rows of gstride 4-byte granules, zeroed before every pass
     uint64_t gstride;
     uint8_t *advice, *zrow;   // N + 66 bytes each
     int32_t *cand;            // per strip: {bv (L form), by, bx, corner (L form)}

@@ -82,109 +82,22 @@ __device__ __forceinline__ int prof_byte(const typename ProfWord<R>::T &pw, int 
 
 __device__ __forceinline__ int shr1_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false); }
 
-// Inter-strip hand-off of the single-pair kernel: every boundary cell travels as one naturally aligned 8-byte granule
-// {tag = 1, value = T} written by ONE write-through (sc1) store and polled with sc1 loads -- the data is the flag, no
-// fence (cdna_hip_programming.md G16 "R2"); the buffer is zeroed before every launch so tag 0 = not yet produced.
-__device__ __forceinline__ void granule_store(uint64_t *p, int v)
+// Inter-strip hand-off of the single-pair kernel: every boundary cell travels as one naturally aligned 4-byte granule, the
+// T value itself -- T = 4H + 2 is never zero, and the buffer is zeroed before every pass, so "non-zero" means "produced".
+// Written by ONE write-through (sc1) store and polled with sc1 loads: the data is the flag, no fence
+// (cdna_hip_programming.md G16 "R2").
+__device__ __forceinline__ void granule_store(uint32_t *p, int v)
 {
-    __hip_atomic_store(p, (1ull << 32) | (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, (uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
+__device__ __forceinline__ uint32_t granule_load(const uint32_t *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-
-// ---- single-pair kernel, steady state of the core-local fill: ONE asm statement per step.  A lone wave issues one
-// instruction per ~4-5 cycles whatever its kind (VALU, SALU, LDS, s_nop), so the step is written by hand to the minimum
-// instruction count, with every gfx950 hazard slot (VALU writes VCC -> VALU reads it: 2 wait states; VALU write -> DPP
-// read: 2) filled by useful work:
-//   top-in   lanes 0..3 <- the boundary group G rotated by (k & 15) (row_ror; only lane 0 matters), then lanes 1..63 <-
-//            lane-1's bottom cell (wave_shr:1)
-//   LDS      query offset of step k+2, profile bytes of step k+1 (both complete before the statement ends)
-//   per cell penalty select, three candidate keys, v_max3, T form, Beginning tag, direction bits, end-cell tracker
-//   bottom   cell -> 64-deep lane shift register towards lane 63's publisher (wave_shl:1)
-// `two` is 2 in every lane except lane 0 of strip 0, which holds an impossible T: row 1's carried penalty comes from the
-// advice (not from the border above), and this path only runs over column groups whose advice bits are all zero.
-#define ALN_S_HEAD(ROR, PWREAD)                                                                                \
-    "v_mov_b32_dpp %[tin], %[G] " ROR " row_mask:0x1 bank_mask:0x1\n\t"                                      \
-    "v_mov_b32_dpp %[tin], %[TL] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                  \
-    "v_cmp_eq_u32 vcc, %[two], %[tin]\n\t"                                                                    \
-    "ds_read_u16 %[qvn], %[qop] offset:%[qoff]\n\t"                                                          \
-    "v_add_u32 %[la], %[prow], %[qvc]\n\t"                                                                   \
-    PWREAD " %[pwn], %[la]\n\t"
-#define ALN_S_TAIL                                                                                             \
-    "v_mov_b32_dpp %[on], %[oo] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"                                    \
-    "s_waitcnt lgkmcnt(0)"
-#define ALN_S_BODY1                                                                                            \
-    "v_add_u32_sdwa %[c0], %[hd], sext(%[pwc]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
-    "v_cndmask_b32 %[np], %[ne], %[nd], vcc\n\t"                                                              \
-    "v_add_u32 %[ta], %[tin], %[np]\n\t"                                                                      \
-    "v_add3_u32 %[tb], %[TL], %[np], -1\n\t"                                                                  \
-    "v_max3_i32 %[k0], %[ta], %[tb], %[c0]\n\t"                                                               \
-    "v_and_or_b32 %[TL], %[k0], -4, 2\n\t"                                                                    \
-    "v_max_u32 %[k0], %[k0], 3\n\t"                                                                           \
-    "v_mov_b32 %[on], %[TL]\n\t"                                                                           \
-    "v_lshl_add_u32 %[p0], %[TL], 11, %[kt]\n\t"                                                              \
-    "v_alignbit_b32 %[dw], %[k0], %[dw], 2\n\t"                                                               \
-    "v_max_i32 %[r0], %[r0], %[p0]\n\t"
-// R = 2: row 1's diagonal is row 0's previous cell, its top is row 0's new cell
-#define ALN_S_BODY2                                                                                            \
-    "v_add_u32_sdwa %[c0], %[hd], sext(%[pwc]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t" \
-    "v_add_u32_sdwa %[c1], %[T0], sext(%[pwc]) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t" \
-    "v_cndmask_b32 %[np], %[ne], %[nd], vcc\n\t"                                                              \
-    "v_add_u32 %[ta], %[tin], %[np]\n\t"                                                                      \
-    "v_add3_u32 %[tb], %[T0], %[np], -1\n\t"                                                                  \
-    "v_max3_i32 %[k0], %[ta], %[tb], %[c0]\n\t"                                                               \
-    "v_cmp_gt_u32 vcc, 3, %[k0]\n\t"                                                                          \
-    "v_and_or_b32 %[T0], %[k0], -4, 2\n\t"                                                                    \
-    "v_max_u32 %[k0], %[k0], 3\n\t"                                                                           \
-    "v_cndmask_b32 %[np], %[ne], %[nd], vcc\n\t"                                                              \
-    "v_add_u32 %[ta], %[T0], %[np]\n\t"                                                                       \
-    "v_add3_u32 %[tb], %[TL], %[np], -1\n\t"                                                                  \
-    "v_max3_i32 %[c1], %[ta], %[tb], %[c1]\n\t"                                                               \
-    "v_alignbit_b32 %[dw], %[k0], %[dw], 2\n\t"                                                               \
-    "v_and_or_b32 %[TL], %[c1], -4, 2\n\t"                                                                    \
-    "v_max_u32 %[c1], %[c1], 3\n\t"                                                                           \
-    "v_mov_b32 %[on], %[TL]\n\t"                                                                           \
-    "v_lshl_add_u32 %[p0], %[T0], 11, %[kt]\n\t"                                                              \
-    "v_alignbit_b32 %[dw], %[c1], %[dw], 2\n\t"                                                               \
-    "v_max_i32 %[r0], %[r0], %[p0]\n\t"                                                                       \
-    "v_lshl_add_u32 %[p0], %[TL], 11, %[kt]\n\t"                                                              \
-    "v_max_i32 %[r1], %[r1], %[p0]\n\t"
-
-// lane-local state of the asm step (all VGPRs) -- the same quantities FastStrip carries through its C++ step
-struct SingleRegs {
-    int T0, TL;               // this lane's cells of the previous column (T form); R = 1 uses TL only
-    int r0, r1;               // packed end-cell trackers
-    int hd;                   // diagonal of row 0: the cell that came in from above one step ago
-    uint32_t dw;              // direction bits
-    uint32_t pw, qv;          // profile bytes of this step / query offset of the next step's profile read
-    int outq;                 // publisher shift register
-};
-template <int R, int NR>
-__device__ __forceinline__ void single_step_asm(SingleRegs &s, int G, int two, uint32_t qop, uint32_t prow, int ne, int nd, int kt)
-{
-    int tin, np, ta, tb, c0, c1, k0, p0, on;
-    uint32_t qvn, pwn, la;
-#define ALN_S_OPERANDS                                                                                         \
-    : [tin] "=&v"(tin), [np] "=&v"(np), [ta] "=&v"(ta), [tb] "=&v"(tb), [c0] "=&v"(c0), [c1] "=&v"(c1),      \
-      [k0] "=&v"(k0), [p0] "=&v"(p0), [on] "=&v"(on), [qvn] "=&v"(qvn), [pwn] "=&v"(pwn), [la] "=&v"(la),     \
-      [T0] "+v"(s.T0), [TL] "+v"(s.TL), [r0] "+v"(s.r0), [r1] "+v"(s.r1), [dw] "+v"(s.dw)                     \
-    : [G] "v"(G), [two] "v"(two), [qop] "v"(qop), [prow] "v"(prow), [qvc] "v"(s.qv), [pwc] "v"(s.pw),         \
-      [hd] "v"(s.hd), [ne] "v"(ne), [nd] "v"(nd), [oo] "v"(s.outq), [kt] "s"(kt), [qoff] "n"(2 * NR + 4),      \
-      [nr] "n"(NR)                                                                                             \
-    : "vcc"
-    if constexpr (R == 1) {
-        if constexpr (NR == 0) asm volatile(ALN_S_HEAD("quad_perm:[0,1,2,3]", "ds_read_u8") ALN_S_BODY1 ALN_S_TAIL ALN_S_OPERANDS);
-        else asm volatile(ALN_S_HEAD("row_ror:%[nr]", "ds_read_u8") ALN_S_BODY1 ALN_S_TAIL ALN_S_OPERANDS);
-    } else {
-        if constexpr (NR == 0) asm volatile(ALN_S_HEAD("quad_perm:[0,1,2,3]", "ds_read_u16") ALN_S_BODY2 ALN_S_TAIL ALN_S_OPERANDS);
-        else asm volatile(ALN_S_HEAD("row_ror:%[nr]", "ds_read_u16") ALN_S_BODY2 ALN_S_TAIL ALN_S_OPERANDS);
-    }
-#undef ALN_S_OPERANDS
-    s.hd = tin; s.pw = pwn; s.qv = qvn; s.outq = on;
-}
+// ---- single-pair kernel, steady state of the core-local fill: one asm statement per 16-column unit, generated by
+// tools/gen_single_asm.py (see there for the schedule and the hazards it honours).
+#include "aln_single_unit.inc"
 
 // Everything a strip needs that is uniform over the pair.  Passed BY VALUE so that it lives in (scalar) registers.
 struct FastIn {
@@ -200,6 +113,7 @@ struct FastIn {
     uint8_t *advice, *zrow;
     int *ckpt;
     bool hazard;
+    bool adv_any;             // single-pair kernel: the advice may hold non-zero bytes (second and later passes)
     bool store_dirs;          // false: score-only (the packed directions are not written)
     bool pwm;                 // position-weight-matrix scoring (batch kernels only)
     const uint32_t *pwm_words;// per column: int8 scores 4*s - 2 of residues 0..3
@@ -207,8 +121,8 @@ struct FastIn {
     uint32_t last_flip;
     uint16_t *qo_pad;         // single-pair kernel: LDS, q[x] * 64R at index x + 63, zeros elsewhere (N + 192 entries)
     int *bring;               // single-pair kernel: LDS, 2 x 64 ints
-    const uint64_t *gin;      // single-pair kernel: granule rows
-    uint64_t *gout;
+    const uint32_t *gin;      // single-pair kernel: granule rows
+    uint32_t *gout;
     uint32_t *abort_flag;
 };
 
@@ -229,6 +143,15 @@ __device__ __forceinline__ bool better_i(int v, uint32_t y, uint32_t x, int bv, 
     if (SEM == ALN_CORE_LOCAL) return y < by || (y == by && x < bx);     // first in row-major order (simple/mod.rs:212)
     return x > bx || (x == bx && y > by);                                 // last in column-major order (aligner_core.rs:224)
 }
+
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t uniform64(const void *p) { return uniform64((uint64_t)(uintptr_t)p); }
 
 template <int SEM, int R, bool SINGLE, bool FIRST, bool LAST>
 struct FastStrip {
@@ -253,11 +176,13 @@ struct FastStrip {
     const uint8_t *qo_lane;    // &qo_pad[63 - lane] (u16 entries: q[x] * 64R, zero padded on both sides)
     int *bring;                // 2 x 64 T values of the row above this strip
     int qv, top0v;
-    uint64_t gpre;             // prefetched granule of the next 16-column group (lanes 0..15)
+    uint32_t gpre;             // prefetched granule of the next 16-column group (lanes 0..15)
     // hand-written steady state (single-pair kernel, core local, R <= 2)
-    static constexpr bool ASMPATH = SINGLE && SEM == ALN_CORE_LOCAL && (R == 1 || R == 2);
+    static constexpr bool ASMPATH = SINGLE && SEM == ALN_CORE_LOCAL && (R == 1 || R == 2) && !(FIRST && LAST);
     int twov;                  // 2; lane 0 of strip 0: a value no cell takes (row 1's penalty never follows the border)
-    uint64_t advmask;          // strip 0: which of the 64 advice bytes in advchunk are set
+    PW pw1;                    // steady format (see steady_enter)
+    uint32_t qv2, qv3, gA, gB;
+    bool insteady;
 
     __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s)
         : in(i), strip(s), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
@@ -277,13 +202,13 @@ struct FastStrip {
         if constexpr (!SINGLE) {
             return (xi < N) ? in.brow[xi + 1] : 2;
         } else {
-            const uint64_t *src = in.gin + xi;
-            uint64_t g = 0;
+            const uint32_t *src = in.gin + xi;
+            uint32_t g = 0;
             uint32_t spins = 0;
             for (;;) {
                 const bool need = xi < N;
                 if (need) g = granule_load(src);
-                if (__all(!need || (g >> 32) != 0)) break;
+                if (__all(!need || g != 0)) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 if (spins > (1u << 22) ||
@@ -294,7 +219,7 @@ struct FastStrip {
                     break;
                 }
             }
-            return (xi < N) ? (int)(uint32_t)g : 2;
+            return (xi < N) ? (int)g : 2;
         }
     }
 
@@ -405,9 +330,9 @@ struct FastStrip {
     {
         const uint32_t col = 16u * j + (uint32_t)lane;
         const bool need = lane < 16 && col < N;
-        uint64_t g = gpre;
+        uint32_t g = gpre;
         uint32_t spins = 0;
-        while (!__all(!need || (g >> 32) != 0)) {
+        while (!__all(!need || g != 0)) {
             __builtin_amdgcn_s_sleep(1);
             if (need) g = granule_load(in.gin + col);
             ++spins;
@@ -419,9 +344,9 @@ struct FastStrip {
                 break;
             }
         }
-        if (lane < 16) bring[col & 127u] = need ? (int)(uint32_t)g : 2;
+        if (lane < 16) bring[col & 127u] = need ? (int)g : 2;
         const uint32_t ncol = col + 16u;
-        gpre = (lane < 16 && ncol < N) ? granule_load(in.gin + ncol) : 0ull;       // group j+1, consumed next time
+        gpre = (lane < 16 && ncol < N) ? granule_load(in.gin + ncol) : 0u;       // group j+1, consumed next time
     }
 
     // four blocks of SPB steps -> one 16-byte store per lane (1 KiB per wave, coalesced).  The block loop is a real
@@ -433,105 +358,107 @@ struct FastStrip {
         if (SINGLE && SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) reinterpret_cast<uint32_t *>(in.zrow)[block] = dw;
     }
 
-    // 16 steady-state steps through the asm step (R = 1: one block, R = 2: two blocks), w0 / w1 = their direction words
-    template <int B>
-    __device__ __forceinline__ void asm_block(SingleRegs &sr, const int G, const uint32_t qop, const uint32_t prow32, const int kt0)
+    // ---- steady state of the single-pair core-local kernel (ASMPATH): whole quads through the generated asm loop.
+    // Lane state in "steady format": pw / pw1 = profile bytes of the next two steps, qv2 / qv3 = query offsets of the two
+    // after them (the C++ step keeps pw of this step and qv of the next one only); gA / gB = boundary groups of the
+    // next even / odd 16-column unit, in the lane order row_ror hands them to lane 0 (lane i of every row of 16 holds
+    // column ku + (16 - i) % 16).
+    __device__ __forceinline__ void steady_enter(const uint32_t k)
     {
+        pw1 = *reinterpret_cast<const PW *>(prow + qv);
+        qv2 = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 2));
+        qv3 = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 3));
+        gA = 0; gB = 0;
+        if (!FIRST) {
+            const uint32_t *src = in.gin + k + ((16u - (uint32_t)lane) & 15u);
+            const uint32_t g0 = granule_load(src), g1 = granule_load(src + 16);
+            if ((k >> 4) & 1u) { gB = g0; gA = g1; } else { gA = g0; gB = g1; }
+        }
+        insteady = true;
+    }
+    // back to the C++ step at step k (a multiple of 16): its LDS ring needs column group k / 16 and its prefetch register
+    // the group after that
+    __device__ __forceinline__ void steady_leave(const uint32_t k)
+    {
+        qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 1));
+        if (!FIRST) { gpre = 0; stage_boundary16(k >> 4); top0v = bring[k & 127u]; }
+        insteady = false;
+    }
+    // quads [kb, kb_end) -- see tools/gen_single_asm.py for what the statement does and why it is one statement
+    __device__ __forceinline__ void steady_run(const uint32_t kb, const uint32_t kb_end)
+    {
+        uint32_t ku = uniform32(kb * SPB);
+        const uint32_t kend = uniform32(kb_end * SPB);
+        uint32_t qop = (uint32_t)(uintptr_t)qo_lane + 2u * ku;
+        const uint32_t prow32 = (uint32_t)(uintptr_t)prow;
+        int kt = (int)uniform32(2047u - (ku & 2047u));
+        int G = 2, X1, O1, np, ta, tb, c0, c1, k0, p0;
+        uint32_t P0 = (uint32_t)pw, P1 = (uint32_t)pw1, P2, P3, Q0, Q1, Q2 = qv2, Q3 = qv3, la, w0, w1, w2, w3, st, spin;
+        uint32_t vsrc = 4u * (ku + ((16u - (uint32_t)lane) & 15u));
+        uint32_t vpub = 4u * (ku + (uint32_t)lane - 111u);
+        uint32_t vdir = (kb >> 2) * 1024u + (uint32_t)lane * 16u;
+        uint32_t vz = 4u * kb;
+        const uint32_t vzero = 0;
+        const uint64_t m48 = uniform64(0xffff000000000000ull), zmask = uniform64(zsel_on ? (1ull << lb) : 0ull);
+        const uint32_t sdirs = uniform32(in.store_dirs ? 1u : 0u);
+        uint8_t *dbase = reinterpret_cast<uint8_t *>(in.dirw) + (size_t)strip * (size_t)aln_uniform_strip_bytes(N, R);
+        int dummyT = 2, dummyR = INT_MIN;                     // R = 1 has one row: its asm never touches T0 / r1
+        int &t0ref = (R == 1) ? dummyT : Tl[0];
+        int &r1ref = (R == 1) ? dummyR : rbv[R - 1];
+        // wave-uniform addresses, pinned to SGPR pairs (the "s" constraint alone does not move a value out of VGPRs)
+        const uint64_t sgin = uniform64(in.gin), sgout = uniform64(in.gout), sdbase = uniform64(dbase),
+                       szbase = uniform64(in.zrow), sabort = uniform64(in.abort_flag);
+#define ALN_STEADY_OPERANDS                                                                                    \
+        : [T0] "+&v"(t0ref), [TL] "+&v"(Tl[R - 1]), [r0] "+&v"(rbv[0]), [r1] "+&v"(r1ref), [X0] "+&v"(hdiag),       \
+          [O0] "+&v"(outq), [P0] "+&v"(P0), [P1] "+&v"(P1), [Q2] "+&v"(Q2), [Q3] "+&v"(Q3), [gA] "+&v"(gA), [gB] "+&v"(gB),  \
+          [G] "+&v"(G), [qop] "+&v"(qop), [vsrc] "+&v"(vsrc), [vpub] "+&v"(vpub), [vdir] "+&v"(vdir), [vz] "+&v"(vz),       \
+          [kt] "+&s"(kt), [ku] "+&s"(ku), [st] "=&s"(st), [spin] "=&s"(spin), [w0] "=&v"(w0), [w1] "=&v"(w1),           \
+          [w2] "=&v"(w2), [w3] "=&v"(w3), [P2] "=&v"(P2), [P3] "=&v"(P3), [Q0] "=&v"(Q0), [Q1] "=&v"(Q1),             \
+          [X1] "=&v"(X1), [O1] "=&v"(O1), [np] "=&v"(np), [ta] "=&v"(ta), [tb] "=&v"(tb), [c0] "=&v"(c0),             \
+          [c1] "=&v"(c1), [k0] "=&v"(k0), [p0] "=&v"(p0), [la] "=&v"(la)                                              \
+        : [two] "v"(twov), [prow] "v"(prow32), [ne] "v"(in.ne4), [nd] "v"(in.nd4), [vzero] "v"(vzero),               \
+          [kend] "s"(kend), [gin] "s"(sgin), [gout] "s"(sgout), [dbase] "s"(sdbase), [zbase] "s"(szbase),         \
+          [abortp] "s"(sabort), [m48] "s"(m48), [zmask] "s"(zmask), [sdirs] "s"(sdirs)                         \
+        : "vcc", "scc", "memory"
         if constexpr (R == 1) {
-            single_step_asm<1, 0>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 0);
-            single_step_asm<1, 1>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 1);
-            single_step_asm<1, 2>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 2);
-            single_step_asm<1, 3>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 3);
-            single_step_asm<1, 4>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 4);
-            single_step_asm<1, 5>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 5);
-            single_step_asm<1, 6>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 6);
-            single_step_asm<1, 7>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 7);
-            single_step_asm<1, 8>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 8);
-            single_step_asm<1, 9>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 9);
-            single_step_asm<1, 10>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 10);
-            single_step_asm<1, 11>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 11);
-            single_step_asm<1, 12>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 12);
-            single_step_asm<1, 13>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 13);
-            single_step_asm<1, 14>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 14);
-            single_step_asm<1, 15>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - 15);
+            if constexpr (FIRST) asm volatile(ALN_STEADY_ASM_R1_FIRST ALN_STEADY_OPERANDS);
+            else if constexpr (LAST) asm volatile(ALN_STEADY_ASM_R1_LAST ALN_STEADY_OPERANDS);
+            else asm volatile(ALN_STEADY_ASM_R1_MID ALN_STEADY_OPERANDS);
         } else {
-            single_step_asm<2, B + 0>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 0);
-            single_step_asm<2, B + 1>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 1);
-            single_step_asm<2, B + 2>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 2);
-            single_step_asm<2, B + 3>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 3);
-            single_step_asm<2, B + 4>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 4);
-            single_step_asm<2, B + 5>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 5);
-            single_step_asm<2, B + 6>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 6);
-            single_step_asm<2, B + 7>(sr, G, twov, qop, prow32, in.ne4, in.nd4, kt0 - B - 7);
+            if constexpr (FIRST) asm volatile(ALN_STEADY_ASM_R2_FIRST ALN_STEADY_OPERANDS);
+            else if constexpr (LAST) asm volatile(ALN_STEADY_ASM_R2_LAST ALN_STEADY_OPERANDS);
+            else asm volatile(ALN_STEADY_ASM_R2_MID ALN_STEADY_OPERANDS);
+        }
+#undef ALN_STEADY_OPERANDS
+        pw = (PW)P0; pw1 = (PW)P1; qv2 = Q2; qv3 = Q3;
+        bottom = Tl[R - 1];
+        if (st != 0) {                                        // the producer never arrived: poison the run
+            if (lane == 0) __hip_atomic_store(in.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            aborted = true;
         }
     }
-
-    // steady-state quad of the single-pair core-local kernel: 16-column units through the asm step; a unit of strip 0
-    // whose advice bits are not all zero takes the C++ step (rare: second and later passes only)
-    __device__ __forceinline__ void quad_asm(uint4 *dirq, const uint32_t kb)
+    // strip 0, second and later passes: first quad in [kb, kb_end) one of whose columns carries a non-zero advice byte
+    // (kb_end if none).  Lane j scans the 16 bytes of columns base + 16 j ..: 1024 columns per sweep.
+    __device__ __forceinline__ uint32_t advice_free_until(const uint32_t kb, const uint32_t kb_end)
     {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        const uint32_t prow32 = (uint32_t)(uintptr_t)prow;
-#pragma unroll 1
-        for (uint32_t u = 0; u < 4u / R; ++u) {
-            const uint32_t ku = (kb + u * R) * SPB;                     // first step of the unit, a multiple of 16
-            bool slow = false;
-            if (FIRST && in.hazard) {
-                if ((ku & 63u) == 0) {
-                    const uint32_t xi = ku + (uint32_t)lane;
-                    advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
-                    advmask = __ballot(advchunk != 0);
-                }
-                slow = ((advmask >> (ku & 63u)) & 0xffffull) != 0;
-            }
-            if (slow) {
-                if (!FIRST) top0v = bring[ku & 127u];
-#pragma unroll 1
-                for (uint32_t jj = 0; jj < (uint32_t)R; ++jj) {
-                    const uint32_t k0 = ku + jj * SPB;
-                    if (!FIRST && ((k0 + SPB) & 15u) == 0) stage_boundary16((k0 + SPB) >> 4);
+        const uint32_t k_end = kb_end * SPB;
+        for (uint32_t k = kb * SPB; k < k_end; k += 1024u) {
+            uint32_t any = 0;
+            const uint32_t x0 = k + 16u * (uint32_t)lane;     // step k of lane 0 is column x = k + 1
 #pragma unroll
-                    for (int kk = 0; kk < SPB; ++kk) step<false>(k0 + kk);
-                    if (!LAST && ((k0 + SPB) & 15u) == 0) publish(k0 + SPB - 1);
-                    const uint32_t w = u * R + jj;
-                    if (w == 0) v.x = dw; else if (w == 1) v.y = dw; else if (w == 2) v.z = dw; else v.w = dw;
-                    store_zdw(kb + w);
-                }
-                continue;
+            for (int i = 0; i < 16; ++i) any |= (x0 + i < N) ? (uint32_t)in.advice[x0 + i + 1] : 0u;
+            const uint64_t m = __ballot(any != 0);
+            if (m) {
+                const uint32_t kq = ((k + 16u * (uint32_t)__builtin_ctzll(m)) / (4u * SPB)) * 4u;   // block index of that quad
+                return kq < kb_end ? kq : kb_end;
             }
-            // boundary cells of columns ku .. ku+15 in the order row_ror hands them to lane 0
-            int G = 2;
-            if (!FIRST) G = bring[(ku + ((16u - (uint32_t)lane) & 15u)) & 127u];
-            SingleRegs sr;
-            sr.T0 = Tl[0]; sr.TL = Tl[R - 1]; sr.r0 = rbv[0]; sr.r1 = rbv[R - 1]; sr.hd = hdiag; sr.dw = dw;
-            sr.pw = (uint32_t)pw; sr.qv = (uint32_t)qv; sr.outq = outq;
-            const uint32_t qop = (uint32_t)(uintptr_t)qo_lane + 2u * ku;
-            const int kt0 = (int)(2047u - (ku & 2047u));
-            if constexpr (R == 1) {
-                if (!FIRST) stage_boundary16((ku + 16u) >> 4);
-                asm_block<0>(sr, G, qop, prow32, kt0);
-                if (u == 0) v.x = sr.dw; else if (u == 1) v.y = sr.dw; else if (u == 2) v.z = sr.dw; else v.w = sr.dw;
-            } else {
-                asm_block<0>(sr, G, qop, prow32, kt0);
-                if (u == 0) v.x = sr.dw; else v.z = sr.dw;
-                if (zsel_on && (uint32_t)lane == lb) reinterpret_cast<uint32_t *>(in.zrow)[kb + 2 * u] = sr.dw;
-                if (!FIRST) stage_boundary16((ku + 16u) >> 4);
-                asm_block<8>(sr, G, qop, prow32, kt0);
-                if (u == 0) v.y = sr.dw; else v.w = sr.dw;
-            }
-            if (R > 1) { Tl[0] = sr.T0; rbv[R - 1] = sr.r1; }
-            Tl[R - 1] = sr.TL; rbv[0] = sr.r0; hdiag = sr.hd; dw = sr.dw;
-            pw = (PW)sr.pw; qv = (int)sr.qv; outq = sr.outq; bottom = sr.TL;
-            if (!LAST) publish(ku + 15u);
-            store_zdw(kb + u * R + (R - 1));
         }
-        if (in.store_dirs) dirq[(size_t)(kb >> 2) * 64] = v;
+        return kb_end;
     }
 
     template <bool MASKED>
     __device__ __forceinline__ void quad(uint4 *dirq, const uint32_t kb)
     {
-        if constexpr (!MASKED && ASMPATH) { quad_asm(dirq, kb); return; }
         uint4 v = make_uint4(0, 0, 0, 0);
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; ++j) {
@@ -629,11 +556,11 @@ struct FastStrip {
         bottom = Tl[R - 1];
         inchunk = 2; qchunk = 0; advchunk = 0; dw = 0; outq = 0; qv = 0; top0v = 2;
         twov = (FIRST && lane == 0) ? 1 : 2;                 // T is always 2 (mod 4)
-        advmask = 0;
+        pw1 = PW{}; qv2 = 0; qv3 = 0; gA = 0; gB = 0; insteady = false;
         if constexpr (SINGLE) {
             qo_lane = reinterpret_cast<const uint8_t *>(in.qo_pad + 63 - lane);
             bring = in.bring;
-            gpre = (!FIRST && lane < 16 && (uint32_t)lane < N) ? granule_load(in.gin + lane) : 0ull;
+            gpre = (!FIRST && lane < 16 && (uint32_t)lane < N) ? granule_load(in.gin + lane) : 0u;
             if (!FIRST) { stage_boundary16(0); top0v = bring[0]; }
             qoff = *reinterpret_cast<const uint16_t *>(qo_lane);                      // step 0: column -lane
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2);                    // step 1
@@ -660,8 +587,28 @@ struct FastStrip {
             if (next_ck != 0xffffffffu) seg_end = min(seg_end, next_ck / SPB);
             const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
             for (; kb < e0; kb += 4) quad<true>(dirq, kb);
+            if constexpr (ASMPATH) {
+                while (kb < e1 && !aborted) {
+                    uint32_t kb_to = e1;
+                    if (FIRST && in.adv_any) {
+                        kb_to = advice_free_until(kb, e1);
+                        if (kb_to == kb) {                       // this quad has advice: the C++ step handles it
+                            if (insteady) steady_leave(kb * SPB);
+                            const uint32_t xi = ((kb * SPB) & ~63u) + (uint32_t)lane;   // the step reloads it every 64 steps only
+                            advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
+                            quad<false>(dirq, kb);
+                            kb += 4;
+                            continue;
+                        }
+                    }
+                    if (!insteady) steady_enter(kb * SPB);
+                    steady_run(kb, kb_to);
+                    kb = kb_to;
+                }
+                if (aborted) { o.aborted = true; return o; }
+                if (insteady && kb >= kb_steady1) steady_leave(kb * SPB);
+            }
             for (; kb < e1; kb += 4) quad<false>(dirq, kb);
-            if (ASMPATH && !FIRST) top0v = bring[(kb * SPB) & 127u];     // the C++ step reads its boundary cell one step ahead
             for (; kb < seg_end; kb += 4) quad<true>(dirq, kb);
             if (ckmode && kb < nkb && kb * SPB == next_ck) {
                 if (in.ck_mode == 1) checkpoint(slot, true);

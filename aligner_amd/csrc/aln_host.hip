@@ -83,7 +83,7 @@ struct aln_batch {
     std::vector<uint32_t> single_pairs;
     std::vector<uint32_t> single_r;
     size_t n_small = 0;
-    uint64_t *d_granules = nullptr;
+    uint32_t *d_granules = nullptr;
     uint64_t granule_bytes = 0;
     uint8_t *d_advice1 = nullptr;
     int32_t *d_cand = nullptr;
@@ -285,7 +285,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
                 b->single_pairs.push_back((uint32_t)i);
                 b->single_r.push_back(R);
                 const uint64_t gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
-                b->granule_bytes = std::max<uint64_t>(b->granule_bytes, std::max<uint64_t>((uint64_t)ns * gstride * 8, 4ull * (d.M + 2)));
+                b->granule_bytes = std::max<uint64_t>(b->granule_bytes, std::max<uint64_t>((uint64_t)ns * gstride * 4, 4ull * (d.M + 2)));
                 b->single_max_n = std::max(b->single_max_n, std::max(d.N, ns));
                 b->tbmap_entries = std::max<uint64_t>(b->tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
             }
@@ -451,7 +451,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), s);
         for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
             sa.pass = pass;
-            HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 8, s));
+            HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 4, s));
             aln_launch_single(&sa, lds, pass + 1 == sa.max_passes ? 1 : 0, s);
             b->fill_launches++;
         }

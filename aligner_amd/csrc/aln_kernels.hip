@@ -437,6 +437,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     in.t = a.seqs + desc.t_off;
     in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
     in.hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
+    in.adv_any = false;
     in.ck_mode = 0; in.last_flip = 0;
     in.store_dirs = a.store_dirs != 0;
     in.pwm = a.pwm != 0;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
     in.nd4 = -4 * (int)a.del;
     in.ne4 = -4 * (int)a.ext;
     in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr; in.qo_pad = nullptr; in.bring = nullptr;
-    in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.store_dirs = true; in.pwm = false; in.pwm_words = nullptr; in.ck_mode = 0; in.last_flip = 0;
+    in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.adv_any = false; in.store_dirs = true; in.pwm = false; in.pwm_words = nullptr; in.ck_mode = 0; in.last_flip = 0;
     uint32_t pair;
     while (next_pair(a, in.lane, pair)) {
         PairDesc &desc = a.descs[pair];
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
     in.brow = nullptr; in.brow0 = nullptr; in.ckpt = nullptr;
     in.advice = a.advice; in.zrow = a.zrow;
     in.hazard = a.hazard != 0;
+    in.adv_any = a.hazard != 0 && a.pass != 0;
     in.store_dirs = a.store_dirs != 0;
     in.pwm = false; in.pwm_words = nullptr;
     in.ck_mode = 0; in.last_flip = 0;

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generates aligner_amd/csrc/aln_single_unit.inc: the hand-scheduled gfx950 instruction stream of the steady state of
+the single-pair core-local fill (one wave = one strip, lane = R consecutive rows, anti-diagonal skew; aln_fast.cuh).
+
+Why asm, and why ONE statement for the whole steady loop.  A lone wave issues one instruction per ~4-5 cycles whatever
+its kind (VALU, SALU, LDS, s_nop) and nothing hides a memory round trip for it, so the loop is written to the minimum
+instruction count with every hazard slot filled by useful work, and it never waits on memory:
+  * LDS: the two reads of a step (profile bytes, query offset) are issued two steps before their use (4-deep register
+    rotation, s_waitcnt lgkmcnt(2));
+  * boundary cells from the strip above arrive as 4-byte granules (the T value, never zero; the row is zeroed before
+    every pass).  The loads of the next TWO 16-column groups are always in flight (gA / gB by unit parity).  A hand-off
+    costs about a microsecond, and gfx9 may complete loads and stores out of order with respect to each other, so no
+    vmcnt count can be trusted here: the destination register is ZEROED before the load is issued and simply read when
+    the group is due -- all 16 values non-zero <=> the load has landed AND the producer had published.  Only then
+    (rare: start of the strip, or a consumer that caught up) the wave drains, re-loads and polls, bounded, watching
+    the abort word.
+  * stores (bottom row to the strip below, direction words, bottom-row record of the last strip) are fire-and-forget.
+Everything that is in flight is drained before the statement ends, so every output is valid when the compiler sees it.
+
+Per step i (k = ku + i):
+  top-in   X' <- lanes 0..3: boundary group G rotated by i (row_ror; only lane 0 matters); lanes 1..63: lane-1's bottom
+           cell (wave_shr:1)
+  LDS      P[(i+2)%4] <- profile bytes of step i+2 (address = prow + Q[(i+2)%4]);  Q[i%4] <- query offset of step i+4
+  cells    penalty select (Beginning above -> del, else ext), three candidate keys, v_max3, T form, Beginning tag,
+           2 direction bits, packed end-cell tracker
+  bottom   cell -> 64-deep lane shift register towards lane 63's publisher (wave_shl:1)
+gfx950 hazards honoured by construction: VALU writes VCC -> VALU reads VCC needs 2 wait states; VALU writes a VGPR -> DPP
+reads it needs 2.
+
+Variants: R in {1, 2} x {FIRST (no strip above: G = 2), MID, LAST (no strip below; records its bottom row)}.
+Run:  python tools/gen_single_asm.py   (rewrites the .inc; the build does not run it)
+"""
+import os
+
+SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_%d"
+
+
+def step(i, R, dw):
+    X_old, X_new = "%%[X%d]" % (i % 2), "%%[X%d]" % ((i + 1) % 2)
+    O_old, O_new = "%%[O%d]" % (i % 2), "%%[O%d]" % ((i + 1) % 2)
+    P_cur, P_nxt = "%%[P%d]" % (i % 4), "%%[P%d]" % ((i + 2) % 4)
+    Q_adr, Q_nxt = "%%[Q%d]" % ((i + 2) % 4), "%%[Q%d]" % (i % 4)
+    ror = "quad_perm:[0,1,2,3]" if i == 0 else "row_ror:%d" % i
+    pwread = "ds_read_u8" if R == 1 else "ds_read_u16"
+    L = []
+    L.append("v_mov_b32_dpp %s, %%[G] %s row_mask:0x1 bank_mask:0x1" % (X_new, ror))
+    L.append("v_mov_b32_dpp %s, %%[TL] wave_shr:1 row_mask:0xf bank_mask:0xf" % X_new)
+    L.append("v_cmp_eq_u32 vcc, %%[two], %s" % X_new)
+    L.append("s_waitcnt lgkmcnt(2)")
+    L.append("v_add_u32 %%[la], %%[prow], %s" % Q_adr)
+    L.append("%s %s, %%[la]" % (pwread, P_nxt))
+    L.append("ds_read_u16 %s, %%[qop] offset:%d" % (Q_nxt, 2 * (i + 4)))
+    if R == 1:
+        L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
+        L.append("v_cndmask_b32 %[np], %[ne], %[nd], vcc")
+        L.append("v_add_u32 %%[ta], %s, %%[np]" % X_new)
+        L.append("v_add3_u32 %[tb], %[TL], %[np], -1")
+        L.append("v_max3_i32 %[k0], %[ta], %[tb], %[c0]")
+        L.append("v_and_or_b32 %[TL], %[k0], -4, 2")
+        L.append("v_max_u32 %[k0], %[k0], 3")
+        L.append("v_mov_b32 %s, %%[TL]" % O_new)
+        L.append("v_lshl_add_u32 %[p0], %[TL], 11, %[kt]")
+        L.append("v_alignbit_b32 %s, %%[k0], %s, 2" % (dw, dw))
+        L.append("v_max_i32 %[r0], %[r0], %[p0]")
+    else:
+        # row 1's diagonal is row 0's previous cell, its top is row 0's new cell
+        L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
+        L.append("v_add_u32_sdwa %%[c1], %%[T0], sext(%s) %s" % (P_cur, SDWA % 1))
+        L.append("v_cndmask_b32 %[np], %[ne], %[nd], vcc")
+        L.append("v_add_u32 %%[ta], %s, %%[np]" % X_new)
+        L.append("v_add3_u32 %[tb], %[T0], %[np], -1")
+        L.append("v_max3_i32 %[k0], %[ta], %[tb], %[c0]")
+        L.append("v_cmp_gt_u32 vcc, 3, %[k0]")
+        L.append("v_and_or_b32 %[T0], %[k0], -4, 2")
+        L.append("v_max_u32 %[k0], %[k0], 3")
+        L.append("v_cndmask_b32 %[np], %[ne], %[nd], vcc")
+        L.append("v_add_u32 %[ta], %[T0], %[np]")
+        L.append("v_add3_u32 %[tb], %[TL], %[np], -1")
+        L.append("v_max3_i32 %[c1], %[ta], %[tb], %[c1]")
+        L.append("v_alignbit_b32 %s, %%[k0], %s, 2" % (dw, dw))
+        L.append("v_and_or_b32 %[TL], %[c1], -4, 2")
+        L.append("v_max_u32 %[c1], %[c1], 3")
+        L.append("v_mov_b32 %s, %%[TL]" % O_new)
+        L.append("v_lshl_add_u32 %[p0], %[T0], 11, %[kt]")
+        L.append("v_alignbit_b32 %s, %%[c1], %s, 2" % (dw, dw))
+        L.append("v_max_i32 %[r0], %[r0], %[p0]")
+        L.append("v_lshl_add_u32 %[p0], %[TL], 11, %[kt]")
+        L.append("v_max_i32 %[r1], %[r1], %[p0]")
+    L.append("v_mov_b32_dpp %s, %s wave_shl:1 row_mask:0xf bank_mask:0xf" % (O_new, O_old))
+    L.append("s_sub_u32 %[kt], %[kt], 1")
+    return L
+
+
+def acquire(u, uid):
+    """Group of unit u (register gA / gB by parity) -> G; request the group two units on into the same register."""
+    g = "%[gA]" if u % 2 == 0 else "%[gB]"
+    L = []
+    L.append("v_mov_b32 %%[G], %s" % g)
+    L.append("v_cmp_ne_u32 vcc, 0, %[G]")
+    L.append("s_cmp_eq_u64 vcc, exec")
+    L.append("s_cbranch_scc1 Lrdy%d_%s" % (u, uid))
+    # ---- not there: drain (a load merely late), then re-load and poll while the producer has not published
+    L.append("s_mov_b32 %[spin], 0")
+    L.append("Lpoll%d_%s:" % (u, uid))
+    L.append("s_waitcnt vmcnt(0)")
+    L.append("v_mov_b32 %%[G], %s" % g)
+    L.append("v_cmp_ne_u32 vcc, 0, %[G]")
+    L.append("s_cmp_eq_u64 vcc, exec")
+    L.append("s_cbranch_scc1 Lrdy%d_%s" % (u, uid))
+    L.append("s_sleep 1")
+    L.append("global_load_dword %s, %%[vsrc], %%[gin] sc1" % g)
+    L.append("s_add_u32 %[spin], %[spin], 1")
+    L.append("s_and_b32 %[st], %[spin], 0x3ff")
+    L.append("s_cmp_lg_u32 %[st], 0")
+    L.append("s_cbranch_scc1 Lpoll%d_%s" % (u, uid))
+    # every 1024 polls: has the run been poisoned?  (and give up after 2^22 polls: poison it ourselves)
+    L.append("global_load_dword %[G], %[vzero], %[abortp] sc1")
+    L.append("s_waitcnt vmcnt(0)")
+    L.append("v_readfirstlane_b32 %[st], %[G]")
+    L.append("s_cmp_lg_u32 %[st], 0")
+    L.append("s_cbranch_scc1 Labort_%s" % uid)
+    L.append("s_cmp_lt_u32 %[spin], 0x400000")
+    L.append("s_cbranch_scc1 Lpoll%d_%s" % (u, uid))
+    L.append("s_branch Labort_%s" % uid)
+    L.append("Lrdy%d_%s:" % (u, uid))
+    L.append("v_mov_b32 %s, 0" % g)
+    L.append("global_load_dword %s, %%[vsrc], %%[gin] offset:128 sc1" % g)
+    L.append("v_add_u32 %[vsrc], 64, %[vsrc]")
+    return L
+
+
+def loop(R, kind):
+    U = 4 // R                      # units per quad
+    uid = "%="
+    L = []
+    L.append("Lloop_%s:" % uid)
+    for u in range(U):
+        if kind != "FIRST":
+            L += acquire(u, uid)
+        for i in range(16):
+            if R == 1:
+                dw = "%%[w%d]" % u
+            else:
+                dw = "%%[w%d]" % (2 * u + (0 if i < 8 else 1))
+            L += step(i, R, dw)
+        L.append("v_add_u32 %[qop], 32, %[qop]")
+        if kind != "LAST":
+            # lanes 48..63 of the shift register hold the bottom cells of columns ku-63 .. ku-48
+            L.append("s_mov_b64 exec, %[m48]")
+            L.append("global_store_dword %[vpub], %[O0], %[gout] sc1")
+            L.append("s_mov_b64 exec, -1")
+            L.append("v_add_u32 %[vpub], 64, %[vpub]")
+        else:
+            # the lane that owns row M records its direction words (tag 3 <=> H == 0), one per block
+            L.append("s_mov_b64 exec, %[zmask]")
+            if R == 1:
+                L.append("global_store_dword %%[vz], %%[w%d], %%[zbase]" % u)
+            else:
+                L.append("global_store_dword %%[vz], %%[w%d], %%[zbase]" % (2 * u))
+                L.append("global_store_dword %%[vz], %%[w%d], %%[zbase] offset:4" % (2 * u + 1))
+            L.append("s_mov_b64 exec, -1")
+            L.append("v_add_u32 %%[vz], %d, %%[vz]" % (4 * R))
+    # the quad's direction words: 16 bytes per lane, 1 KiB per wave
+    L.append("s_cmp_eq_u32 %[sdirs], 0")
+    L.append("s_cbranch_scc1 Lnodir_%s" % uid)
+    for j in range(4):
+        L.append("global_store_dword %%[vdir], %%[w%d], %%[dbase] offset:%d" % (j, 4 * j))
+    L.append("Lnodir_%s:" % uid)
+    L.append("v_add_u32 %[vdir], 0x400, %[vdir]")
+    L.append("s_add_u32 %%[ku], %%[ku], %d" % (16 * U))
+    L.append("s_cmp_lt_u32 %[ku], %[kend]")
+    L.append("s_cbranch_scc1 Lloop_%s" % uid)
+    L.append("s_mov_b32 %[st], 0")
+    L.append("s_branch Lexit_%s" % uid)
+    L.append("Labort_%s:" % uid)
+    L.append("s_mov_b32 %[st], 1")
+    L.append("Lexit_%s:" % uid)
+    L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return L
+
+
+def main():
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "aligner_amd", "csrc", "aln_single_unit.inc")
+    with open(out, "w") as f:
+        f.write("// GENERATED by tools/gen_single_asm.py -- do not edit.  Steady-state loop of the single-pair core-local fill.\n")
+        for R in (1, 2):
+            for kind in ("FIRST", "MID", "LAST"):
+                lines = loop(R, kind)
+                n = sum(1 for ln in lines if not ln.endswith(":"))
+                f.write("// R = %d, %s strip: %d instructions per quad of %d steps\n" % (R, kind, n, 64 // R))
+                f.write("#define ALN_STEADY_ASM_R%d_%s \\\n" % (R, kind))
+                for j, ln in enumerate(lines):
+                    last = j + 1 == len(lines)
+                    f.write('    "%s%s"%s\n' % (ln, "" if last else "\\n\\t", "" if last else " \\"))
+                f.write("\n")
+    print("wrote", os.path.normpath(out))
+
+
+if __name__ == "__main__":
+    main()
