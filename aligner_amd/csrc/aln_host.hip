@@ -25,6 +25,7 @@ extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s);
+extern "C" void aln_launch_traceback_expand_single(const TraceArgs *a, uint32_t pair, hipStream_t s);
 extern "C" void aln_launch_single(const SingleArgs *a, uint32_t lds_bytes, int with_serial, hipStream_t s);
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
@@ -472,6 +473,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
             tsa.R = b->single_r[j]; tsa.ns = (d.M + 64 * tsa.R - 1) / (64 * tsa.R);
             tsa.map = b->d_tbmap; tsa.seg = b->d_tbmap + (uint64_t)tsa.ns * (d.N + 1);
             aln_launch_traceback_single(&tsa, d.N, s);
+            aln_launch_traceback_expand_single(&ta, tsa.pair, s);
         }
         aln_launch_traceback_expand(&ta, s);
         HIPCHK(hipGetLastError());

@@ -892,50 +892,115 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
 }
 
 // ---------------------------------------------------------------- parallel traceback of one large pair
+// A window of a strip's packed direction words staged in LDS: quads [q_lo, q_lo + q_n) (a quad = 4 blocks x 64 lanes x
+// 4 B = 1 KiB, contiguous in memory: aln_dir_word_index).  A walk moves up and left, i.e. towards smaller wave steps, so
+// the window ends at the quad of the largest step the block's walks start from; whatever leaves it falls back to global.
+struct StripWindow {
+    const uint32_t *wbase;
+    const uint32_t *lds;
+    uint32_t q_lo, q_n;
+};
+// cooperative copy (16 B per thread, coalesced) of the window that ends at wave step k_hi; call from every thread
+__device__ __forceinline__ StripWindow stage_window(const uint32_t *wbase, uint32_t *lds, uint32_t lds_quads, uint32_t k_hi,
+                                                    uint32_t lgR)
+{
+    StripWindow w;
+    const uint32_t sh = 4u - lgR;                                  // log2(steps per block)
+    const uint32_t q_hi = k_hi >> (sh + 2);
+    w.wbase = wbase; w.lds = lds;
+    w.q_n = min(lds_quads, q_hi + 1u);
+    w.q_lo = q_hi + 1u - w.q_n;
+    const uint4 *src = reinterpret_cast<const uint4 *>(wbase) + (size_t)w.q_lo * 64u;
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    // blocks of 256 threads, at most 48 quads: 12 x 16 B per thread, all loads in flight before the first LDS write
+    const uint32_t n = w.q_n * 64u;
+    uint4 v[12];
+#pragma unroll
+    for (uint32_t j = 0; j < 12; ++j) {
+        const uint32_t i = threadIdx.x + j * 256u;
+        if (i < n) v[j] = src[i];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 12; ++j) {
+        const uint32_t i = threadIdx.x + j * 256u;
+        if (i < n) dst[i] = v[j];
+    }
+    __syncthreads();
+    return w;
+}
+
 // Walks from (cy, cx) while the walk stays inside the strip whose rows are y0+1 .. (uniform-R layout), following the
 // same rules as aln_traceback_kernel.  Returns true if the walk ended (Beginning / origin), false if it left the strip
-// upwards (then cy == y0).  `ops` (optional) receives the tags.
-__device__ __forceinline__ bool walk_in_strip(const uint32_t *wbase, uint32_t y0, uint32_t lgR, uint32_t N, bool global,
+// upwards (then cy == y0).  `ops` (optional) receives the tags.  fetch(kb, lane) returns the direction word of block kb
+// of that lane.  The interior loop is branch-lean (one exit test, one load, shifts); the borders of the global
+// semantics (D[0][x] = Left, D[y][0] = Top: simple/mod.rs:55-67) are whole runs and are handled after it.
+template <class Fetch>
+__device__ __forceinline__ bool walk_in_strip(Fetch fetch, uint32_t y0, uint32_t lgR, uint32_t N, bool global,
                                               uint32_t &cy, uint32_t &cx, uint32_t &steps, uint8_t *ops)
 {
     const uint32_t R = 1u << lgR, sh = 4u - lgR;
-    for (;;) {
-        if (cy == 0 || cx == 0) {
-            if (!global || (cy == 0 && cx == 0)) return true;            // Beginning (simple/mod.rs:55-57)
-            if (cy == 0) { if (ops) ops[steps] = 1; ++steps; --cx; continue; }      // D[0][x] = Left
-            if (ops) ops[steps] = 2;                                      // D[y][0] = Top
-            ++steps; --cy;
-            if (cy <= y0) return cy == 0 && false;
-            continue;
-        }
-        if (cy <= y0) return false;
-        const uint32_t i = cy - 1 - y0;
+    uint32_t y = cy, x = cx, n = steps;
+    bool beginning = false;
+    bool go = (y > y0 && x != 0);
+    while (go) {                                       // single exit, body predicated: the loop is one exec-mask update
+        const uint32_t i = y - 1 - y0;
         const uint32_t lane = i >> lgR, r = i & (R - 1u);
-        const uint32_t k = cx - 1 + lane, kb = k >> sh;
-        const uint32_t word = wbase[(((uint64_t)(kb >> 2) * 64u + lane) << 2) + (kb & 3u)];
-        const uint32_t bend = (kb << sh) + (1u << sh) - 1u, lend = lane + N - 1u;
-        const uint32_t e = min(bend, lend);
+        const uint32_t k = x - 1 + lane, kb = k >> sh;
+        const uint32_t word = fetch(kb, lane);
+        const uint32_t e = min((kb << sh) + (1u << sh) - 1u, lane + N - 1u);
         const uint32_t tag = (word >> (30u - 2u * (((e - k) << lgR) + (R - 1u - r)))) & 3u;
-        if (tag == 3u) return true;
-        if (ops) ops[steps] = (uint8_t)tag;
-        ++steps;
-        cy -= (tag != 1u); cx -= (tag != 2u);
+        beginning = (tag == 3u);
+        if (ops && !beginning) ops[n] = (uint8_t)tag;
+        n += beginning ? 0u : 1u;
+        y -= (tag == 0u || tag == 2u) ? 1u : 0u;       // 0 Diagonal, 1 Left, 2 Top (3 moves nothing)
+        x -= (tag <= 1u) ? 1u : 0u;
+        go = !beginning && y > y0 && x != 0;
     }
+    bool ended = beginning;
+    if (!beginning) {
+        if (!global) ended = (y == 0 || x == 0);                         // local: every border cell is Beginning
+        else if (y == 0) {                                               // top border: Left all the way to the origin
+            if (ops) for (uint32_t j = 0; j < x; ++j) ops[n + j] = 1;
+            n += x; x = 0; ended = true;
+        } else if (x == 0) {                                             // left border: Top until the strip is left
+            const uint32_t run = y - y0;
+            if (ops) for (uint32_t j = 0; j < run; ++j) ops[n + j] = 2;
+            n += run; y = y0; ended = false;
+        }
+    }
+    cy = y; cx = x; steps = n;
+    return ended;
 }
+// LDS quads of the traceback kernels' window: 768 wave steps (48 KiB at most)
+__host__ __device__ inline uint32_t tb_window_quads(uint32_t R) { const uint32_t q = 12u * R; return q > 48u ? 48u : q; }
 
-// exit map: thread (x, s) enters strip s on its bottom row at column x
+// exit map: thread (x, s) enters strip s on its bottom row at column x; the block's 256 walks share one staged window
 extern "C" __global__ __launch_bounds__(256) void aln_tb_single_maps_kernel(TraceSingleArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_words[];
     const PairDesc &d = a.descs[a.pair];
     if (a.results[a.pair].status != ALN_OK || (d.layout & 0xffu) != ALN_LAYOUT_UNIFORM) return;   // serial fallback: aln_traceback_kernel
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (x > d.N) return;
     const uint32_t lgR = 31u - (uint32_t)__builtin_clz(a.R), rows = 64u << lgR;
     const uint32_t y0 = s * rows;
     const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
-    uint32_t cy = min(d.M, y0 + rows), cx = x, steps = 0;
-    const bool stopped = walk_in_strip(wbase, y0, lgR, d.N, global, cy, cx, steps, nullptr);
+    const uint32_t cy0 = min(d.M, y0 + rows);
+    const uint32_t x_hi = min(d.N, blockIdx.x * blockDim.x + blockDim.x - 1u);
+    const uint32_t k_hi = (x_hi ? x_hi - 1u : 0u) + ((cy0 - 1u - y0) >> lgR);
+    const StripWindow w = stage_window(wbase, smem_words, tb_window_quads(a.R), k_hi, lgR);
+    if (x > d.N) return;
+    uint32_t cy = cy0, cx = x, steps = 0;
+    const uint32_t q_lo = w.q_lo, q_n = w.q_n;
+    // LDS through an address-space-3 pointer: a generic pointer would turn the two loads into one flat_load with a select
+    const __attribute__((address_space(3))) uint32_t *lds3 = (const __attribute__((address_space(3))) uint32_t *)smem_words;
+    auto fetch = [&](uint32_t kb, uint32_t lane) -> uint32_t {
+        const uint32_t q = kb >> 2, rel = q - q_lo;
+        uint32_t word = lds3[((min(rel, q_n - 1u) * 64u + lane) << 2) + (kb & 3u)];            // ds_read, always in range
+        if (__builtin_expect(rel >= q_n, 0)) word = wbase[(((uint64_t)q * 64u + lane) << 2) + (kb & 3u)];   // left the window (rare)
+        return word;
+    };
+    const bool stopped = walk_in_strip(fetch, y0, lgR, d.N, global, cy, cx, steps, nullptr);
     a.map[(size_t)s * (d.N + 1) + x] = make_uint4(cx, cy, steps, stopped ? 1u : 0u);
 }
 
@@ -963,8 +1028,9 @@ extern "C" __global__ void aln_tb_single_chain_kernel(TraceSingleArgs a)
         // first segment: from the end cell, which need not be on the strip's bottom row
         a.seg[s] = make_uint4(cy, cx, 0, 1);
         const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
+        auto fetch = [&](uint32_t kb, uint32_t lane) -> uint32_t { return wbase[(((uint64_t)(kb >> 2) * 64u + lane) << 2) + (kb & 3u)]; };
         uint32_t steps = 0;
-        stopped = walk_in_strip(wbase, s * rows, lgR, d.N, global, cy, cx, steps, nullptr);
+        stopped = walk_in_strip(fetch, s * rows, lgR, d.N, global, cy, cx, steps, nullptr);
         off = steps;
         while (!stopped && s > 0) {
             --s;
@@ -981,10 +1047,12 @@ extern "C" __global__ void aln_tb_single_chain_kernel(TraceSingleArgs a)
     res.aln_len = off + 1;
 }
 
-// one thread per strip: re-walks its segment and writes the tags at their final offset
-extern "C" __global__ __launch_bounds__(64) void aln_tb_single_segments_kernel(TraceSingleArgs a)
+// one block per strip: stages the window its segment starts in, then one thread re-walks the segment and writes the
+// tags at their final offset
+extern "C" __global__ __launch_bounds__(256) void aln_tb_single_segments_kernel(TraceSingleArgs a)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_words[];
+    const uint32_t s = blockIdx.x;
     if (s >= a.ns) return;
     const PairDesc &d = a.descs[a.pair];
     if (a.results[a.pair].status != ALN_OK || (d.layout & 0xffu) != ALN_LAYOUT_UNIFORM) return;
@@ -995,7 +1063,65 @@ extern "C" __global__ __launch_bounds__(64) void aln_tb_single_segments_kernel(T
     uint8_t *ops = a.tb + d.tb_off + 2ull * (d.N + d.M + 2) + sg.z;
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
     uint32_t cy = sg.x, cx = sg.y, steps = 0;
-    walk_in_strip(wbase, s * rows, lgR, d.N, global, cy, cx, steps, ops);
+    const uint32_t y0 = s * rows;
+    const uint32_t k_hi = (cx ? cx - 1u : 0u) + ((cy > y0 ? cy - 1u - y0 : 0u) >> lgR);
+    const StripWindow w = stage_window(wbase, smem_words, tb_window_quads(a.R), k_hi, lgR);
+    const uint32_t q_lo = w.q_lo, q_n = w.q_n;
+    // LDS through an address-space-3 pointer: a generic pointer would turn the two loads into one flat_load with a select
+    const __attribute__((address_space(3))) uint32_t *lds3 = (const __attribute__((address_space(3))) uint32_t *)smem_words;
+    auto fetch = [&](uint32_t kb, uint32_t lane) -> uint32_t {
+        const uint32_t q = kb >> 2, rel = q - q_lo;
+        uint32_t word = lds3[((min(rel, q_n - 1u) * 64u + lane) << 2) + (kb & 3u)];            // ds_read, always in range
+        if (__builtin_expect(rel >= q_n, 0)) word = wbase[(((uint64_t)q * 64u + lane) << 2) + (kb & 3u)];   // left the window (rare)
+        return word;
+    };
+    if (threadIdx.x == 0) walk_in_strip(fetch, y0, lgR, d.N, global, cy, cx, steps, ops);
+}
+
+// Pass 2 for one large pair: one block of 1024 threads (the per-pair wave of aln_traceback_expand_kernel would take
+// ~100 us for 20 000 tags).  Same arithmetic: each thread sums its contiguous slice, block-wide exclusive scan, replay.
+extern "C" __global__ __launch_bounds__(1024) void aln_tb_single_expand_kernel(TraceArgs a, uint32_t pair)
+{
+    __shared__ uint32_t wsum_y[16], wsum_x[16];
+    const PairDesc &d = a.descs[pair];
+    const aln_pair_result &res = a.results[pair];
+    if (res.status != ALN_OK || (d.layout & 0xffu) != ALN_LAYOUT_UNIFORM) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint8_t *__restrict__ q = a.seqs + d.q_off;
+    const uint8_t *__restrict__ t = a.seqs + d.t_off;
+    const uint32_t cap = d.N + d.M + 2;
+    uint8_t *__restrict__ qa = a.tb + d.tb_off;
+    uint8_t *__restrict__ ta = qa + cap;
+    const uint8_t *__restrict__ ops = a.tb + d.tb_off + 2ull * cap;
+    const uint32_t len = res.aln_len - 1u;
+    const uint32_t per = (len + 1023u) / 1024u;
+    const uint32_t lo = min(len, tid * per), hi = min(len, lo + per);
+    uint32_t dy = 0, dx = 0;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t tag = ops[len - 1 - j];
+        dx += (tag != 2u); dy += (tag != 1u);
+    }
+    uint32_t sy = dy, sx = dx;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t oy = (uint32_t)__shfl_up((int)sy, m), ox = (uint32_t)__shfl_up((int)sx, m);
+        if ((int)lane >= m) { sy += oy; sx += ox; }
+    }
+    if (lane == 63) { wsum_y[wave] = sy; wsum_x[wave] = sx; }
+    __syncthreads();
+    uint32_t by = 0, bx = 0;
+    for (uint32_t wv = 0; wv < wave; ++wv) { by += wsum_y[wv]; bx += wsum_x[wv]; }
+    uint32_t py = res.start_y + by + sy - dy, px = res.start_x + bx + sx - dx;
+    for (uint32_t j = lo; j < hi; ++j) {
+        const uint32_t tag = ops[len - 1 - j];
+        px += (tag != 2u); py += (tag != 1u);
+        qa[j] = (tag == 2u) ? a.blank : q[px - 1];
+        ta[j] = (tag == 1u) ? a.blank : t[py - 1];
+    }
+    if (tid == 0) {
+        qa[len] = q[res.end_x - 1];                     // the duplicated seed pair
+        ta[len] = t[res.end_y - 1];
+    }
 }
 
 // Pass 2, one wave per pair: turns the tag string into the two aligned code strings in final (forward) order.
@@ -1009,6 +1135,7 @@ extern "C" __global__ __launch_bounds__(256) void aln_traceback_expand_kernel(Tr
     const PairDesc &d = a.descs[pair];
     const aln_pair_result &res = a.results[pair];
     if (res.status != ALN_OK) return;
+    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) return;      // large pairs: aln_tb_single_expand_kernel
     const uint8_t *__restrict__ q = a.seqs + d.q_off;
     const uint8_t *__restrict__ t = a.seqs + d.t_off;
     const uint32_t cap = d.N + d.M + 2;
@@ -1121,9 +1248,14 @@ extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s)
 }
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s)
 {
-    hipLaunchKernelGGL(aln_tb_single_maps_kernel, dim3((N + 1 + 255) / 256, a->ns), dim3(256), 0, s, *a);
+    const uint32_t lds = tb_window_quads(a->R) * 1024u;
+    hipLaunchKernelGGL(aln_tb_single_maps_kernel, dim3((N + 1 + 255) / 256, a->ns), dim3(256), lds, s, *a);
     hipLaunchKernelGGL(aln_tb_single_chain_kernel, dim3(1), dim3(64), 0, s, *a);
-    hipLaunchKernelGGL(aln_tb_single_segments_kernel, dim3((a->ns + 63) / 64), dim3(64), 0, s, *a);
+    hipLaunchKernelGGL(aln_tb_single_segments_kernel, dim3(a->ns), dim3(256), lds, s, *a);
+}
+extern "C" void aln_launch_traceback_expand_single(const TraceArgs *a, uint32_t pair, hipStream_t s)
+{
+    hipLaunchKernelGGL(aln_tb_single_expand_kernel, dim3(1), dim3(1024), 0, s, *a, pair);
 }
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s)
