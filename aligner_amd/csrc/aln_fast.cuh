@@ -382,6 +382,10 @@ struct FastStrip {
     {
         qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 1));
         if (!FIRST) { gpre = 0; stage_boundary16(k >> 4); top0v = bring[k & 127u]; }
+        if (FIRST && SEM == ALN_CORE_LOCAL && in.hazard) {       // the step reloads its advice chunk every 64 steps only
+            const uint32_t xi = (k & ~63u) + (uint32_t)lane;
+            advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
+        }
         insteady = false;
     }
     // quads [kb, kb_end) -- see tools/gen_single_asm.py for what the statement does and why it is one statement
@@ -594,8 +598,6 @@ struct FastStrip {
                         kb_to = advice_free_until(kb, e1);
                         if (kb_to == kb) {                       // this quad has advice: the C++ step handles it
                             if (insteady) steady_leave(kb * SPB);
-                            const uint32_t xi = ((kb * SPB) & ~63u) + (uint32_t)lane;   // the step reloads it every 64 steps only
-                            advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
                             quad<false>(dirq, kb);
                             kb += 4;
                             continue;

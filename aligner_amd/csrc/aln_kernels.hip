@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64) void aln_single_finalize_kernel(SingleArgs a)
     if (lane == 0) {
         const int corner = a.cand[4 * (a.ns - 1) + 3] >> 2;
         desc.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
-        write_result<SEM>(res, (double)(bv >> 2), by, bx, (double)corner, N, M, a.pass + 1, 1u);
+        write_result<SEM>(res, (double)(bv >> 2), by, bx, (double)corner, N, M, a.pass + 1, 1u | 2u);
         if (aborted) res.status = ALN_ERR_DEVICE;
     }
 }
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(64) void aln_single_serial_kernel(SingleArgs a)
     w.hmat = nullptr; w.store_dirs = a.store_dirs != 0; w.pwm = false;
     serial_fill_impl<int, SEM>(w);
     desc.layout = ALN_LAYOUT_ROWMAJOR;
-    write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, desc.N, desc.M, a.ctrl[15] | 0x80u, 1u);
+    write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, desc.N, desc.M, a.ctrl[15] | 0x80u, 1u | 2u);
 }
 
 // arms pass 0 and clears the advice / bottom-row bytes

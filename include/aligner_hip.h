@@ -85,7 +85,7 @@ typedef struct aln_pair_result {
     uint32_t aln_len;           /* length of both aligned strings (includes the reference's duplicated seed pair) */
     int32_t status;             /* enum aln_status for this pair */
     uint32_t passes;            /* speculative fill passes used (1 unless CORE_LOCAL with del != ext); 0x80|n = serial fallback */
-    uint32_t flags;             /* bit0: integer kernels were used */
+    uint32_t flags;             /* bit0: integer kernels were used; bit1: the strip-pipelined single-pair route */
 } aln_pair_result;
 
 typedef struct aln_ctx aln_ctx;      /* one per process per GPU; thread-safe */
