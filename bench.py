@@ -93,7 +93,11 @@ def main():
     total_cells = int(cells_all.sum())
 
     outs = _ffi.OUT_SCORE | _ffi.OUT_TRACEBACK
-    sb = StagedBatch(batch, _ffi.CORE_LOCAL, 11, 2, S, device=local_rank, outputs=outs)
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter()
+    sb = StagedBatch(batch, _ffi.CORE_LOCAL, 11, 2, S, device=local_rank, outputs=outs)    # device allocs + H2D of the codes
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t_stage
     stream = torch.cuda.Stream()
     rec = RESULT_DTYPE.itemsize
     if world > 1:
@@ -129,7 +133,11 @@ def main():
     sb.enable_timing(False)
 
     # ---- light integrity check outside the timed region: every pair finished OK, gathered records are the shard's
-    res = sb.fetch(want_traceback=False).results
+    t_fetch = time.perf_counter()
+    fetched = sb.fetch(want_traceback=True)              # D2H of the 48-byte summaries and both aligned strings of every pair
+    t_fetch = time.perf_counter() - t_fetch
+    res = fetched.results
+    del fetched
     ok = int((res["status"] == 0).sum())
     refills = int((res["passes"] > 1).sum())
     if world > 1:
@@ -167,6 +175,9 @@ def main():
                          "fill_only_gcups_rank0": round(batch.cells / fill_s / 1e9, 3),
                          "direction_bytes_stored": sb.direction_bytes,
                          "valu_frac": round(batch.cells / fill_s * 16 / 78.6e12, 5)},
+            # never `value`: the same job when the boundary hands over HOST buffers (one staging + one step + one fetch)
+            "pcie_inclusive": {"stage_ms": round(t_stage * 1e3, 2), "fetch_ms": round(t_fetch * 1e3, 2),
+                               "gcups_rank0": round(batch.cells / (t_stage + elapsed / args.steps + t_fetch) / 1e9, 2)},
         }
 
     # ---- N = 1 extras: the single-pair configuration and the CPU baseline
