@@ -99,6 +99,10 @@ __device__ __forceinline__ uint32_t granule_load(const uint32_t *p)
 // tools/gen_single_asm.py (see there for the schedule and the hazards it honours).
 #include "aln_single_unit.inc"
 
+// LDS hand-off ring between two waves of a workgroup: T values (never zero) by column & (ALN_RING - 1); a slot is zeroed
+// by the consumer when it has taken it, and written by the producer only when it is zero.
+#define ALN_RING 4096u
+
 // Everything a strip needs that is uniform over the pair.  Passed BY VALUE so that it lives in (scalar) registers.
 struct FastIn {
     int lane;
@@ -123,6 +127,9 @@ struct FastIn {
     int *bring;               // single-pair kernel: LDS, 2 x 64 ints
     const uint32_t *gin;      // single-pair kernel: granule rows
     uint32_t *gout;
+    uint32_t lds_scratch;           // single-pair kernel: LDS address of 512 scratch bytes (256-aligned), see steady_run
+    uint32_t *ring_in, *ring_out;   // single-pair kernel: LDS rings (ALN_RING entries, aligned to their size) when the
+                                    // strip above / below is a wave of this workgroup, else null (granule rows)
     uint32_t *abort_flag;
 };
 
@@ -183,6 +190,7 @@ struct FastStrip {
     PW pw1;                    // steady format (see steady_enter)
     uint32_t qv2, qv3, gA, gB;
     bool insteady;
+    bool ring_staged;          // LDS hand-off: the C++ step has already taken the next group out of the ring (it is in bring)
 
     __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s)
         : in(i), strip(s), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
@@ -320,7 +328,18 @@ struct FastStrip {
     {
         const uint32_t c = k - 63u;
         const uint32_t col = c - 63u + (uint32_t)lane;              // wraps for lanes that hold nothing yet
-        if (lane >= 48 && col < N) granule_store(in.gout + col, outq);
+        const bool mine = lane >= 48 && col < N;
+        if (in.ring_out) {                                          // the consumer is a wave of this workgroup
+            uint32_t *slot = in.ring_out + (col & (ALN_RING - 1u));
+            uint32_t spins = 0;
+            while (__any(mine && __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0)) {
+                __builtin_amdgcn_s_sleep(1);                        // ring full: the consumer is a whole lap behind
+                if (++spins > (1u << 22)) { aborted = true; break; }
+            }
+            if (mine) __hip_atomic_store(slot, (uint32_t)outq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+        if (mine) granule_store(in.gout + col, outq);
     }
 
     // single-pair kernel: boundary cells arrive 16 columns at a time.  The granules of group j+1 are requested when
@@ -330,6 +349,25 @@ struct FastStrip {
     {
         const uint32_t col = 16u * j + (uint32_t)lane;
         const bool need = lane < 16 && col < N;
+        if (in.ring_in) {                                           // the producer is a wave of this workgroup
+            uint32_t *slot = in.ring_in + (col & (ALN_RING - 1u));
+            uint32_t g = 0, spins = 0;
+            for (;;) {
+                if (need) g = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__all(!need || g != 0)) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if (spins > (1u << 22) ||
+                    ((spins & 1023u) == 0 && __hip_atomic_load(in.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (lane == 0) __hip_atomic_store(in.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    aborted = true;
+                    break;
+                }
+            }
+            if (need) __hip_atomic_store(slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // consumed
+            if (lane < 16) bring[col & 127u] = need ? (int)g : 2;
+            return;
+        }
         uint32_t g = gpre;
         uint32_t spins = 0;
         while (!__all(!need || g != 0)) {
@@ -369,12 +407,13 @@ struct FastStrip {
         qv2 = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 2));
         qv3 = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 3));
         gA = 0; gB = 0;
-        if (!FIRST) {
+        if (!FIRST && !in.ring_in) {
             const uint32_t *src = in.gin + k + ((16u - (uint32_t)lane) & 15u);
             const uint32_t g0 = granule_load(src), g1 = granule_load(src + 16);
             if ((k >> 4) & 1u) { gB = g0; gA = g1; } else { gA = g0; gB = g1; }
         }
         insteady = true;
+        ring_staged = true;
     }
     // back to the C++ step at step k (a multiple of 16): its LDS ring needs column group k / 16 and its prefetch register
     // the group after that
@@ -389,6 +428,9 @@ struct FastStrip {
         insteady = false;
     }
     // quads [kb, kb_end) -- see tools/gen_single_asm.py for what the statement does and why it is one statement
+    // MASKED: quads in which some lane's column does not exist (k - lane < 0 or >= N): the cell update runs under exec =
+    // the lanes whose column exists; hand-over and LDS prefetch run for every lane
+    template <bool MASKED>
     __device__ __forceinline__ void steady_run(const uint32_t kb, const uint32_t kb_end)
     {
         uint32_t ku = uniform32(kb * SPB);
@@ -399,10 +441,29 @@ struct FastStrip {
         int G = 2, X1, O1, np, ta, tb, c0, c1, k0, p0;
         uint32_t P0 = (uint32_t)pw, P1 = (uint32_t)pw1, P2, P3, Q0, Q1, Q2 = qv2, Q3 = qv3, la, w0, w1, w2, w3, st, spin;
         uint32_t vsrc = 4u * (ku + ((16u - (uint32_t)lane) & 15u));
-        uint32_t vpub = 4u * (ku + (uint32_t)lane - 111u);
+        uint32_t vpub = 4u * (ku + (uint32_t)lane - 111u);          // 4 * column (negative while lanes 48..63 hold nothing)
         uint32_t vdir = (kb >> 2) * 1024u + (uint32_t)lane * 16u;
         uint32_t vz = 4u * kb;
         const uint32_t vzero = 0;
+        // LDS hand-off (mode 1): ring slot addresses of this lane's column of the current group / of its published column
+        uint32_t amode = uniform32(in.ring_in ? 1u : 0u), pmode = uniform32(in.ring_out ? 1u : 0u);
+        asm volatile("" : "+s"(amode), "+s"(pmode));          // keep them in SGPRs even when they fold to constants
+        // The asm issues the same LDS operations whatever the mode (its lgkmcnt counts depend on it): with the global
+        // hand-off the ring reads / writes go to scratch words and the step is 0, so the addresses stay put.
+        const uint32_t vrmask = 4u * ALN_RING - 1u;
+        const uint32_t vrbin = in.ring_in ? (uint32_t)(uintptr_t)in.ring_in : in.lds_scratch;
+        const uint32_t vrbout = in.ring_out ? (uint32_t)(uintptr_t)in.ring_out : in.lds_scratch + 256u;
+        uint32_t vrin = in.ring_in ? (vrbin | (vsrc & vrmask)) : vrbin;
+        uint32_t vrout = in.ring_out ? (vrbout | (vpub & vrmask)) : vrbout + 4u * (uint32_t)lane;
+        uint32_t astep = uniform32(in.ring_in ? 64u : 0u), pstep = uniform32(in.ring_out ? 64u : 0u);
+        asm volatile("" : "+s"(astep), "+s"(pstep));
+        // lanes whose column exists at step ku: lane <= ku and ku - lane < N
+        uint64_t em = (ku >= 63u ? ~0ull : ((2ull << ku) - 1ull)) & (ku >= N ? (ku - N + 1u >= 64u ? 0ull : (~0ull << (ku - N + 1u))) : ~0ull), et;
+        em = uniform64(em);
+        int krem = (int)uniform32(N - 1u - ku);
+        const uint32_t n4 = uniform32(4u * N);
+        uint32_t gL = (in.ring_in && ring_staged) ? (uint32_t)bring[(ku + ((16u - (uint32_t)lane) & 15u)) & 127u] : 0u, chk;
+        ring_staged = false;
         const uint64_t m48 = uniform64(0xffff000000000000ull), zmask = uniform64(zsel_on ? (1ull << lb) : 0ull);
         const uint32_t sdirs = uniform32(in.store_dirs ? 1u : 0u);
         uint8_t *dbase = reinterpret_cast<uint8_t *>(in.dirw) + (size_t)strip * (size_t)aln_uniform_strip_bytes(N, R);
@@ -416,15 +477,26 @@ struct FastStrip {
         : [T0] "+&v"(t0ref), [TL] "+&v"(Tl[R - 1]), [r0] "+&v"(rbv[0]), [r1] "+&v"(r1ref), [X0] "+&v"(hdiag),       \
           [O0] "+&v"(outq), [P0] "+&v"(P0), [P1] "+&v"(P1), [Q2] "+&v"(Q2), [Q3] "+&v"(Q3), [gA] "+&v"(gA), [gB] "+&v"(gB),  \
           [G] "+&v"(G), [qop] "+&v"(qop), [vsrc] "+&v"(vsrc), [vpub] "+&v"(vpub), [vdir] "+&v"(vdir), [vz] "+&v"(vz),       \
-          [kt] "+&s"(kt), [ku] "+&s"(ku), [st] "=&s"(st), [spin] "=&s"(spin), [w0] "=&v"(w0), [w1] "=&v"(w1),           \
+          [vrin] "+&v"(vrin), [vrout] "+&v"(vrout), [gL] "+&v"(gL), [chk] "=&v"(chk),                                     \
+          [kt] "+&s"(kt), [ku] "+&s"(ku), [st] "=&s"(st), [spin] "=&s"(spin), [em] "+&s"(em), [et] "=&s"(et), [krem] "+&s"(krem), [w0] "=&v"(w0), [w1] "=&v"(w1), \
           [w2] "=&v"(w2), [w3] "=&v"(w3), [P2] "=&v"(P2), [P3] "=&v"(P3), [Q0] "=&v"(Q0), [Q1] "=&v"(Q1),             \
           [X1] "=&v"(X1), [O1] "=&v"(O1), [np] "=&v"(np), [ta] "=&v"(ta), [tb] "=&v"(tb), [c0] "=&v"(c0),             \
           [c1] "=&v"(c1), [k0] "=&v"(k0), [p0] "=&v"(p0), [la] "=&v"(la)                                              \
         : [two] "v"(twov), [prow] "v"(prow32), [ne] "v"(in.ne4), [nd] "v"(in.nd4), [vzero] "v"(vzero),               \
           [kend] "s"(kend), [gin] "s"(sgin), [gout] "s"(sgout), [dbase] "s"(sdbase), [zbase] "s"(szbase),         \
-          [abortp] "s"(sabort), [m48] "s"(m48), [zmask] "s"(zmask), [sdirs] "s"(sdirs)                         \
+          [abortp] "s"(sabort), [m48] "s"(m48), [zmask] "s"(zmask), [sdirs] "s"(sdirs), [amode] "s"(amode), [n4] "s"(n4), [astep] "s"(astep), [pstep] "s"(pstep), \
+          [pmode] "s"(pmode), [vrmask] "v"(vrmask), [vrbin] "v"(vrbin), [vrbout] "v"(vrbout)                          \
         : "vcc", "scc", "memory"
-        if constexpr (R == 1) {
+        if constexpr (MASKED) {
+            static_assert(!FIRST, "strip 0 runs its ends in C++ (its first column takes del, and nothing waits on its start)");
+            if constexpr (R == 1) {
+                if constexpr (LAST) asm volatile(ALN_MASKED_ASM_R1_LAST ALN_STEADY_OPERANDS);
+                else asm volatile(ALN_MASKED_ASM_R1_MID ALN_STEADY_OPERANDS);
+            } else {
+                if constexpr (LAST) asm volatile(ALN_MASKED_ASM_R2_LAST ALN_STEADY_OPERANDS);
+                else asm volatile(ALN_MASKED_ASM_R2_MID ALN_STEADY_OPERANDS);
+            }
+        } else if constexpr (R == 1) {
             if constexpr (FIRST) asm volatile(ALN_STEADY_ASM_R1_FIRST ALN_STEADY_OPERANDS);
             else if constexpr (LAST) asm volatile(ALN_STEADY_ASM_R1_LAST ALN_STEADY_OPERANDS);
             else asm volatile(ALN_STEADY_ASM_R1_MID ALN_STEADY_OPERANDS);
@@ -560,11 +632,11 @@ struct FastStrip {
         bottom = Tl[R - 1];
         inchunk = 2; qchunk = 0; advchunk = 0; dw = 0; outq = 0; qv = 0; top0v = 2;
         twov = (FIRST && lane == 0) ? 1 : 2;                 // T is always 2 (mod 4)
-        pw1 = PW{}; qv2 = 0; qv3 = 0; gA = 0; gB = 0; insteady = false;
+        pw1 = PW{}; qv2 = 0; qv3 = 0; gA = 0; gB = 0; insteady = false; ring_staged = false;
         if constexpr (SINGLE) {
             qo_lane = reinterpret_cast<const uint8_t *>(in.qo_pad + 63 - lane);
             bring = in.bring;
-            gpre = (!FIRST && lane < 16 && (uint32_t)lane < N) ? granule_load(in.gin + lane) : 0u;
+            gpre = (!FIRST && !in.ring_in && lane < 16 && (uint32_t)lane < N) ? granule_load(in.gin + lane) : 0u;
             if (!FIRST) { stage_boundary16(0); top0v = bring[0]; }
             qoff = *reinterpret_cast<const uint16_t *>(qo_lane);                      // step 0: column -lane
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2);                    // step 1
@@ -590,6 +662,17 @@ struct FastStrip {
             uint32_t seg_end = min(nkb, (chunk_base + 2048u) / SPB);
             if (next_ck != 0xffffffffu) seg_end = min(seg_end, next_ck / SPB);
             const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
+            if constexpr (ASMPATH && !FIRST) {
+                // a strip with a strip above it never leaves the asm: masked quads at both ends (ramp-up, and the tail =
+                // what is left of N after the last full quad + ramp-down), plain quads in between
+                if (!aborted) {
+                    if (!insteady) steady_enter(kb * SPB);
+                    if (kb < e0) { steady_run<true>(kb, e0); kb = e0; }
+                    if (kb < e1 && !aborted) { steady_run<false>(kb, e1); kb = e1; }
+                    if (kb < seg_end && !aborted) { steady_run<true>(kb, seg_end); kb = seg_end; }
+                }
+                if (aborted) { o.aborted = true; return o; }
+            }
             for (; kb < e0; kb += 4) quad<true>(dirq, kb);
             if constexpr (ASMPATH) {
                 while (kb < e1 && !aborted) {
@@ -604,11 +687,11 @@ struct FastStrip {
                         }
                     }
                     if (!insteady) steady_enter(kb * SPB);
-                    steady_run(kb, kb_to);
+                    steady_run<false>(kb, kb_to);
                     kb = kb_to;
                 }
                 if (aborted) { o.aborted = true; return o; }
-                if (insteady && kb >= kb_steady1) steady_leave(kb * SPB);
+                if (FIRST && insteady && kb >= kb_steady1) steady_leave(kb * SPB);   // strip 0 runs its tail in C++
             }
             for (; kb < e1; kb += 4) quad<false>(dirq, kb);
             for (; kb < seg_end; kb += 4) quad<true>(dirq, kb);
@@ -626,7 +709,7 @@ struct FastStrip {
             }
             if (LOCAL && kb * SPB == chunk_base + 2048u) { fold(o, chunk_base); chunk_base += 2048u; }
         }
-        if (SINGLE && !LAST) publish(nkb * SPB - 1);     // the last (up to 15) columns
+        if (SINGLE && !LAST && !(ASMPATH && !FIRST)) publish(nkb * SPB - 1);     // the last (up to 15) columns (the asm publishes after every unit)
         o.brow_bad = o.brow_bad || brow_bad;
         o.aborted = o.aborted || aborted;
         if (ckmode && in.ck_mode == 2) return o;         // ran out of checkpoints: the caller escalates to a full pass

@@ -26,7 +26,7 @@ extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s);
 extern "C" void aln_launch_traceback_expand_single(const TraceArgs *a, uint32_t pair, hipStream_t s);
-extern "C" void aln_launch_single(const SingleArgs *a, uint32_t lds_bytes, int with_serial, hipStream_t s);
+extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_serial, hipStream_t s);
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s);
@@ -447,13 +447,11 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
         sa.store_dirs = b->store_dirs ? 1u : 0u;
         sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
-        const uint32_t lds = (uint32_t)(((uint64_t)sa.rows * sa.cols * 4 + 15) & ~15ull) + ((sa.cols * 64u * sa.R + 15u) & ~15u) +
-                             (((d.N + 192u) * 2u + 15u) & ~15u) + 512u;
         aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), s);
         for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
             sa.pass = pass;
             HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 4, s));
-            aln_launch_single(&sa, lds, pass + 1 == sa.max_passes ? 1 : 0, s);
+            aln_launch_single(&sa, d.N, pass + 1 == sa.max_passes ? 1 : 0, s);
             b->fill_launches++;
         }
         HIPCHK(hipGetLastError());

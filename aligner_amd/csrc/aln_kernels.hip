@@ -438,6 +438,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
     in.hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
     in.adv_any = false;
+    in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0;
     in.ck_mode = 0; in.last_flip = 0;
     in.store_dirs = a.store_dirs != 0;
     in.pwm = a.pwm != 0;
@@ -595,24 +596,45 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
 // Grid = number of strips; strip s consumes the granule row strip s-1 publishes 16 columns at a time, so the strips
 // form a software pipeline across CUs (lag per strip ~ 64 + 63 steps + one L2 round trip).  Every wave that waits
 // polls a bounded number of times and then poisons the run (ctrl[0]) instead of hanging.
-template <int SEM, int R>
-__global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
+// W = 4 (core local, R <= 2, LDS permitting): the four waves of a workgroup own four consecutive strips, one per SIMD,
+// and hand their bottom rows over through LDS rings (a hop costs ~100 cycles instead of ~2 us); only every fourth hop
+// goes through the granule rows.  LDS: [W-1 rings, 16 KiB each, size-aligned] [S] [qo_pad, shared] [per wave: profile,
+// boundary ring of the C++ step].
+template <int SEM, int R, int W>
+__global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
 {
     if (__hip_atomic_load(a.ctrl + 1 + a.pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *S = reinterpret_cast<int *>(smem);
+    constexpr uint32_t RING_BYTES = 4u * ALN_RING;
+    unsigned char *base = smem + (W - 1) * RING_BYTES;
+    int *S = reinterpret_cast<int *>(base);
     const int *gm = reinterpret_cast<const int *>(a.matrix);
     for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
-    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (W - 1) * ALN_RING; i += blockDim.x) reinterpret_cast<uint32_t *>(smem)[i] = 0;
     const PairDesc &desc = a.descs[a.pair];
+    const uint32_t s_bytes = (a.rows * a.cols * 4u + 15u) & ~15u;
+    const uint32_t prof_bytes = (a.cols * 64u * R + 15u) & ~15u;
+    const uint32_t qo_bytes = ((desc.N + 192u) * 2u + 15u) & ~15u;
+    uint16_t *qo_pad = reinterpret_cast<uint16_t *>(base + s_bytes);
+    const uint8_t *qseq = a.seqs + desc.q_off;
+    // query offsets (q[x] * 64R at index x + 63, zero padded), shared by the waves
+    for (uint32_t i = threadIdx.x; i < desc.N + 192u; i += blockDim.x) {
+        const uint32_t x = i - 63u;
+        qo_pad[i] = (i >= 63u && x < desc.N) ? (uint16_t)((uint32_t)qseq[x] * 64u * R) : (uint16_t)0;
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t strip = blockIdx.x * W + wave;
+    if (strip >= a.ns) return;
     FastIn in;
     in.lane = threadIdx.x & 63;
     in.N = desc.N; in.M = desc.M;
-    in.q = a.seqs + desc.q_off;
+    in.q = qseq;
     in.t = a.seqs + desc.t_off;
     in.S = S; in.cols = a.cols;
     in.nd4 = -4 * (int)a.del; in.ne4 = -4 * (int)a.ext;
-    in.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u);
+    in.prof = base + s_bytes + qo_bytes + wave * (prof_bytes + 512u);
+    in.lds_scratch = ((uint32_t)(uintptr_t)(base + s_bytes + qo_bytes + W * (prof_bytes + 512u)) + 255u) & ~255u;   // 512 B, 256-aligned
     in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
     in.brow = nullptr; in.brow0 = nullptr; in.ckpt = nullptr;
     in.advice = a.advice; in.zrow = a.zrow;
@@ -621,21 +643,16 @@ __global__ __launch_bounds__(64) void aln_fill_single_kernel(SingleArgs a)
     in.store_dirs = a.store_dirs != 0;
     in.pwm = false; in.pwm_words = nullptr;
     in.ck_mode = 0; in.last_flip = 0;
-    const uint32_t strip = blockIdx.x;
     const bool last = strip + 1 == a.ns;
     in.gin = a.granules + (uint64_t)(strip ? strip - 1 : 0) * a.gstride;
     in.gout = a.granules + (uint64_t)strip * a.gstride;
+    in.ring_in = (W > 1 && wave > 0) ? reinterpret_cast<uint32_t *>(smem + (wave - 1) * RING_BYTES) : nullptr;
+    in.ring_out = (W > 1 && wave + 1 < W && !last) ? reinterpret_cast<uint32_t *>(smem + wave * RING_BYTES) : nullptr;
     in.abort_flag = a.ctrl;
     FastOut o;
     o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
-    // LDS: query offsets (q[x] * 64R at index x + 63, zero padded) and the boundary ring
-    const uint32_t prof_bytes = (a.cols * 64u * R + 15u) & ~15u;
-    in.qo_pad = reinterpret_cast<uint16_t *>(in.prof + prof_bytes);
-    in.bring = reinterpret_cast<int *>(in.prof + prof_bytes + (((desc.N + 192u) * 2u + 15u) & ~15u));
-    for (uint32_t i = threadIdx.x; i < desc.N + 192u; i += 64) {
-        const uint32_t x = i - 63u;
-        in.qo_pad[i] = (i >= 63u && x < desc.N) ? (uint16_t)((uint32_t)in.q[x] * 64u * R) : (uint16_t)0;
-    }
+    in.qo_pad = qo_pad;
+    in.bring = reinterpret_cast<int *>(in.prof + prof_bytes);
     if (strip == 0) {
         if (last) { FastStrip<SEM, R, true, true, true> fs(in, strip); o = fs.run(o); }
         else { FastStrip<SEM, R, true, true, false> fs(in, strip); o = fs.run(o); }
@@ -1213,25 +1230,57 @@ extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_
 #undef ALN_LAUNCH_FAST
 #undef ALN_LAUNCH
 }
-extern "C" void aln_launch_single(const SingleArgs *a, uint32_t lds_bytes, int with_serial, hipStream_t s)
+// LDS bytes of the fill kernel for W waves per workgroup (rings + S + query offsets + per-wave profile and boundary ring)
+extern "C" uint32_t aln_single_lds_bytes(uint32_t rows, uint32_t cols, uint32_t R, uint32_t N, uint32_t W)
 {
-    const dim3 g(a->ns), b(64);
+    const uint32_t s_bytes = (rows * cols * 4u + 15u) & ~15u, prof_bytes = (cols * 64u * R + 15u) & ~15u;
+    const uint32_t qo_bytes = ((N + 192u) * 2u + 15u) & ~15u;
+    return (W - 1u) * 4u * ALN_RING + s_bytes + qo_bytes + W * (prof_bytes + 512u) + 768u;      // + scratch words (aligned up)
+}
+// four strips per workgroup where the hand-written steady state exists and the LDS fits
+extern "C" uint32_t aln_single_waves(int semantics, uint32_t R, uint32_t rows, uint32_t cols, uint32_t N, uint32_t ns)
+{
+    if (getenv("ALN_SINGLE_W1")) return 1;
+    if (semantics != ALN_CORE_LOCAL || R > 2 || ns < 2) return 1;
+    return aln_single_lds_bytes(rows, cols, R, N, 4) <= 150u * 1024u ? 4u : 1u;
+}
+extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_serial, hipStream_t s)
+{
+    const uint32_t W = aln_single_waves(a->semantics, a->R, a->rows, a->cols, N, a->ns);
+    const uint32_t lds_bytes = aln_single_lds_bytes(a->rows, a->cols, a->R, N, W);
+    const dim3 g((a->ns + W - 1) / W), b(64 * W);
+    const uint32_t serial_lds = (a->rows * a->cols * 4u + 15u) & ~15u;
+#define ALN_SINGLE_LAUNCH(SEM, RR, WW)                                                                         \
+    do {                                                                                                       \
+        auto kern = aln_fill_single_kernel<SEM, RR, WW>;                                                       \
+        if (lds_bytes > 64u * 1024u)                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL(kern, g, b, lds_bytes, s, *a);                                                      \
+    } while (0)
 #define ALN_SINGLE(SEM)                                                                                        \
     do {                                                                                                       \
-        if (a->R == 1) hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 1>), g, b, lds_bytes, s, *a);          \
-        else if (a->R == 2) hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 2>), g, b, lds_bytes, s, *a);     \
-        else if (a->R == 4) hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 4>), g, b, lds_bytes, s, *a);     \
-        else hipLaunchKernelGGL((aln_fill_single_kernel<SEM, 8>), g, b, lds_bytes, s, *a);                     \
-        hipLaunchKernelGGL((aln_single_finalize_kernel<SEM>), dim3(1), b, 0, s, *a);                           \
-        if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<SEM>), dim3(1), b, lds_bytes, s, *a);    \
+        if (a->R == 1) ALN_SINGLE_LAUNCH(SEM, 1, 1);                                                           \
+        else if (a->R == 2) ALN_SINGLE_LAUNCH(SEM, 2, 1);                                                      \
+        else if (a->R == 4) ALN_SINGLE_LAUNCH(SEM, 4, 1);                                                      \
+        else ALN_SINGLE_LAUNCH(SEM, 8, 1);                                                                     \
+        hipLaunchKernelGGL((aln_single_finalize_kernel<SEM>), dim3(1), dim3(64), 0, s, *a);                    \
+        if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<SEM>), dim3(1), dim3(64), serial_lds, s, *a); \
     } while (0)
     switch (a->semantics) {
     case ALN_CORE_GLOBAL: ALN_SINGLE(ALN_CORE_GLOBAL); break;
-    case ALN_CORE_LOCAL: ALN_SINGLE(ALN_CORE_LOCAL); break;
+    case ALN_CORE_LOCAL:
+        if (W == 4) {
+            if (a->R == 1) ALN_SINGLE_LAUNCH(ALN_CORE_LOCAL, 1, 4);
+            else ALN_SINGLE_LAUNCH(ALN_CORE_LOCAL, 2, 4);
+            hipLaunchKernelGGL((aln_single_finalize_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(64), 0, s, *a);
+            if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(64), serial_lds, s, *a);
+        } else ALN_SINGLE(ALN_CORE_LOCAL);
+        break;
     case ALN_LEGACY_GLOBAL: ALN_SINGLE(ALN_LEGACY_GLOBAL); break;
     default: ALN_SINGLE(ALN_LEGACY_LOCAL); break;
     }
 #undef ALN_SINGLE
+#undef ALN_SINGLE_LAUNCH
 }
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s)
 {

@@ -35,7 +35,7 @@ import os
 SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_%d"
 
 
-def step(i, R, dw):
+def step(i, R, dw, kind="MID", masked=False):
     X_old, X_new = "%%[X%d]" % (i % 2), "%%[X%d]" % ((i + 1) % 2)
     O_old, O_new = "%%[O%d]" % (i % 2), "%%[O%d]" % ((i + 1) % 2)
     P_cur, P_nxt = "%%[P%d]" % (i % 4), "%%[P%d]" % ((i + 2) % 4)
@@ -46,10 +46,16 @@ def step(i, R, dw):
     L.append("v_mov_b32_dpp %s, %%[G] %s row_mask:0x1 bank_mask:0x1" % (X_new, ror))
     L.append("v_mov_b32_dpp %s, %%[TL] wave_shr:1 row_mask:0xf bank_mask:0xf" % X_new)
     L.append("v_cmp_eq_u32 vcc, %%[two], %s" % X_new)
-    L.append("s_waitcnt lgkmcnt(2)")
+    L.append("WAIT")                                      # for the two reads issued two steps ago (count filled in later)
     L.append("v_add_u32 %%[la], %%[prow], %s" % Q_adr)
-    L.append("%s %s, %%[la]" % (pwread, P_nxt))
-    L.append("ds_read_u16 %s, %%[qop] offset:%d" % (Q_nxt, 2 * (i + 4)))
+    L.append("%s %s, %%[la] ;M" % (pwread, P_nxt))
+    L.append("ds_read_u16 %s, %%[qop] offset:%d ;MQ" % (Q_nxt, 2 * (i + 4)))
+    if i == 8 and kind != "FIRST":
+        # LDS hand-off: the next unit's group is read half a unit ahead (vrin already points at it).  With the global
+        # hand-off vrin points at a scratch LDS word and gL is never looked at.
+        L.append("ds_read_b32 %[gL], %[vrin] ;M")
+    if masked:
+        L.append("s_mov_b64 exec, %[em]")                 # only the lanes whose column exists: 0 <= k - lane < N
     if R == 1:
         L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
         L.append("v_cndmask_b32 %[np], %[ne], %[nd], vcc")
@@ -86,70 +92,160 @@ def step(i, R, dw):
         L.append("v_max_i32 %[r0], %[r0], %[p0]")
         L.append("v_lshl_add_u32 %[p0], %[TL], 11, %[kt]")
         L.append("v_max_i32 %[r1], %[r1], %[p0]")
+    if masked:
+        # next step's lanes: everything moves up one lane, lane 0 stays in while columns remain (krem = N - 1 - k)
+        L.append("s_mov_b64 exec, -1")
+        L.append("s_sub_u32 %[kt], %[kt], 1")
+        L.append("s_lshl_b64 %[em], %[em], 1")
+        L.append("s_cmp_gt_i32 %[krem], 0")
+        L.append("s_cselect_b64 %[et], 1, 0")
+        L.append("s_or_b64 %[em], %[em], %[et]")
+        L.append("s_sub_u32 %[krem], %[krem], 1")
+        L.append("v_mov_b32_dpp %s, %s wave_shl:1 row_mask:0xf bank_mask:0xf" % (O_new, O_old))
+        return L
     L.append("v_mov_b32_dpp %s, %s wave_shl:1 row_mask:0xf bank_mask:0xf" % (O_new, O_old))
     L.append("s_sub_u32 %[kt], %[kt], 1")
     return L
 
 
-def acquire(u, uid):
-    """Group of unit u (register gA / gB by parity) -> G; request the group two units on into the same register."""
-    g = "%[gA]" if u % 2 == 0 else "%[gB]"
+def poll_tail(u, uid, tag, again):
+    """s_sleep, count, every 1024 polls look at the abort word, give up after 2^22 polls."""
     L = []
-    L.append("v_mov_b32 %%[G], %s" % g)
-    L.append("v_cmp_ne_u32 vcc, 0, %[G]")
-    L.append("s_cmp_eq_u64 vcc, exec")
-    L.append("s_cbranch_scc1 Lrdy%d_%s" % (u, uid))
-    # ---- not there: drain (a load merely late), then re-load and poll while the producer has not published
-    L.append("s_mov_b32 %[spin], 0")
-    L.append("Lpoll%d_%s:" % (u, uid))
-    L.append("s_waitcnt vmcnt(0)")
-    L.append("v_mov_b32 %%[G], %s" % g)
-    L.append("v_cmp_ne_u32 vcc, 0, %[G]")
-    L.append("s_cmp_eq_u64 vcc, exec")
-    L.append("s_cbranch_scc1 Lrdy%d_%s" % (u, uid))
     L.append("s_sleep 1")
-    L.append("global_load_dword %s, %%[vsrc], %%[gin] sc1" % g)
     L.append("s_add_u32 %[spin], %[spin], 1")
     L.append("s_and_b32 %[st], %[spin], 0x3ff")
     L.append("s_cmp_lg_u32 %[st], 0")
-    L.append("s_cbranch_scc1 Lpoll%d_%s" % (u, uid))
-    # every 1024 polls: has the run been poisoned?  (and give up after 2^22 polls: poison it ourselves)
+    L.append("s_cbranch_scc1 %s" % again)
     L.append("global_load_dword %[G], %[vzero], %[abortp] sc1")
     L.append("s_waitcnt vmcnt(0)")
     L.append("v_readfirstlane_b32 %[st], %[G]")
     L.append("s_cmp_lg_u32 %[st], 0")
     L.append("s_cbranch_scc1 Labort_%s" % uid)
     L.append("s_cmp_lt_u32 %[spin], 0x400000")
-    L.append("s_cbranch_scc1 Lpoll%d_%s" % (u, uid))
+    L.append("s_cbranch_scc1 %s" % again)
     L.append("s_branch Labort_%s" % uid)
+    return L
+
+
+def acquire(u, uid, masked=False):
+    """Group of unit u -> G.  amode 0: granules in HBM/L2 (register gA / gB by parity; the group two units on is
+    requested into the same register).  amode 1: the producer is a wave of this workgroup and the group sits in an LDS
+    ring (read half a unit ahead into gL; consumed slots are zeroed, which is what lets the producer reuse them)."""
+    g = "%[gA]" if u % 2 == 0 else "%[gB]"
+    L = []
+
+    def ready_test():
+        T = ["v_cmp_ne_u32 vcc, 0, %[G]"]
+        if masked:
+            T.append("s_or_b64 vcc, vcc, %[et]")         # columns >= N are never published
+        T.append("s_cmp_eq_u64 vcc, exec")
+        return T
+
+    if masked:
+        L.append("v_cmp_le_u32 %[et], %[n4], %[vsrc]")   # et: lanes whose column of this group is >= N (vsrc = 4 * column)
+    L.append("s_cmp_eq_u32 %[amode], 0")
+    L.append("s_cbranch_scc0 Lacql%d_%s" % (u, uid))
+    # ---------------- global hand-off
+    L.append("v_mov_b32 %%[G], %s" % g)
+    L += ready_test()
+    L.append("s_cbranch_scc1 Lrdy%d_%s" % (u, uid))
+    L.append("s_mov_b32 %[spin], 0")
+    L.append("Lpoll%d_%s:" % (u, uid))
+    L.append("s_waitcnt vmcnt(0)")                     # a load that was merely late
+    L.append("v_mov_b32 %%[G], %s" % g)
+    L += ready_test()
+    L.append("s_cbranch_scc1 Lrdy%d_%s" % (u, uid))
+    L.append("global_load_dword %s, %%[vsrc], %%[gin] sc1" % g)
+    L += poll_tail(u, uid, "g", "Lpoll%d_%s" % (u, uid))
     L.append("Lrdy%d_%s:" % (u, uid))
     L.append("v_mov_b32 %s, 0" % g)
     L.append("global_load_dword %s, %%[vsrc], %%[gin] offset:128 sc1" % g)
+    L.append("s_branch Lgo%d_%s" % (u, uid))
+    # ---------------- LDS hand-off
+    L.append("Lacql%d_%s:" % (u, uid))
+    L.append("v_mov_b32 %[G], %[gL]")
+    L += ready_test()
+    L.append("s_cbranch_scc1 Lgo%d_%s" % (u, uid))
+    L.append("s_mov_b32 %[spin], 0")
+    L.append("Lpolll%d_%s:" % (u, uid))
+    L.append("ds_read_b32 %[G], %[vrin]")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L += ready_test()
+    L.append("s_cbranch_scc1 Lgo%d_%s" % (u, uid))
+    L += poll_tail(u, uid, "l", "Lpolll%d_%s" % (u, uid))
+    # ---------------- both: the LDS traffic of the main line is the same whatever the mode (the lgkmcnt counts of the
+    # steps depend on it): the consumed ring slots are zeroed -- which is what lets the producer reuse them -- or, with
+    # the global hand-off, a scratch word is (astep = 0 keeps vrin on it)
+    L.append("Lgo%d_%s:" % (u, uid))
+    L.append("ds_write_b32 %[vrin], %[vzero] ;M")
+    L.append("v_add_u32 %[vrin], %[astep], %[vrin]")
+    L.append("v_and_or_b32 %[vrin], %[vrin], %[vrmask], %[vrbin]")
     L.append("v_add_u32 %[vsrc], 64, %[vsrc]")
     return L
 
 
-def loop(R, kind):
+def publish(u, uid, masked=False):
+    """Bottom cells of columns ku-63 .. ku-48 (lanes 48..63 of the shift register) to the strip below.  pmode 0: one
+    write-through store to the granule row.  pmode 1: the consumer is a wave of this workgroup: LDS ring; the slots
+    must have been consumed (zero) -- they were read at the start of the unit (chk), so this costs no LDS round trip.
+    The ds_write is issued in both modes (pmode 0: to scratch words) so that the LDS traffic of the main line is fixed."""
+    L = []
+    mask = "%[m48]"
+    if masked:
+        L.append("v_cmp_le_i32 %[et], 0, %[vpub]")       # ramp-up: lanes 48..63 still hold columns < 0 (vpub = 4 * column)
+        L.append("s_and_b64 %[et], %[et], %[m48]")
+        mask = "%[et]"
+    L.append("s_mov_b64 exec, %s" % mask)
+    L.append("s_cmp_eq_u32 %[pmode], 0")
+    L.append("s_cbranch_scc0 Lpubl%d_%s" % (u, uid))
+    L.append("global_store_dword %[vpub], %[O0], %[gout] sc1")
+    L.append("s_branch Lpubw%d_%s" % (u, uid))
+    L.append("Lpubl%d_%s:" % (u, uid))
+    L.append("v_cmp_ne_u32 vcc, 0, %[chk]")
+    L.append("s_cmp_eq_u64 vcc, 0")
+    L.append("s_cbranch_scc1 Lpubw%d_%s" % (u, uid))
+    # ring full (the consumer is a whole lap behind): poll until the slots are free
+    L.append("s_mov_b32 %[spin], 0")
+    L.append("Lpubp%d_%s:" % (u, uid))
+    L.append("ds_read_b32 %[chk], %[vrout]")
+    L.append("s_waitcnt lgkmcnt(0)")
+    L.append("v_cmp_ne_u32 vcc, 0, %[chk]")
+    L.append("s_cmp_eq_u64 vcc, 0")
+    L.append("s_cbranch_scc1 Lpubw%d_%s" % (u, uid))
+    L.append("s_sleep 1")
+    L.append("s_add_u32 %[spin], %[spin], 1")
+    L.append("s_cmp_lt_u32 %[spin], 0x400000")
+    L.append("s_cbranch_scc1 Lpubp%d_%s" % (u, uid))
+    L.append("s_mov_b64 exec, -1")
+    L.append("s_branch Labort_%s" % uid)
+    L.append("Lpubw%d_%s:" % (u, uid))
+    L.append("ds_write_b32 %[vrout], %[O0] ;M")
+    L.append("s_mov_b64 exec, -1")
+    L.append("v_add_u32 %[vpub], 64, %[vpub]")
+    L.append("v_add_u32 %[vrout], %[pstep], %[vrout]")
+    L.append("v_and_or_b32 %[vrout], %[vrout], %[vrmask], %[vrbout]")
+    return L
+
+
+def loop(R, kind, masked=False):
     U = 4 // R                      # units per quad
     uid = "%="
     L = []
     L.append("Lloop_%s:" % uid)
     for u in range(U):
         if kind != "FIRST":
-            L += acquire(u, uid)
+            L += acquire(u, uid, masked)
+        if kind != "LAST":
+            L.append("ds_read_b32 %[chk], %[vrout] ;M")      # LDS publish: are this unit's ring slots free? (looked at below)
         for i in range(16):
             if R == 1:
                 dw = "%%[w%d]" % u
             else:
                 dw = "%%[w%d]" % (2 * u + (0 if i < 8 else 1))
-            L += step(i, R, dw)
+            L += step(i, R, dw, kind, masked)
         L.append("v_add_u32 %[qop], 32, %[qop]")
         if kind != "LAST":
-            # lanes 48..63 of the shift register hold the bottom cells of columns ku-63 .. ku-48
-            L.append("s_mov_b64 exec, %[m48]")
-            L.append("global_store_dword %[vpub], %[O0], %[gout] sc1")
-            L.append("s_mov_b64 exec, -1")
-            L.append("v_add_u32 %[vpub], 64, %[vpub]")
+            L += publish(u, uid, masked)
         else:
             # the lane that owns row M records its direction words (tag 3 <=> H == 0), one per block
             L.append("s_mov_b64 exec, %[zmask]")
@@ -176,7 +272,34 @@ def loop(R, kind):
     L.append("s_mov_b32 %[st], 1")
     L.append("Lexit_%s:" % uid)
     L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    return L
+    return fill_waits(L)
+
+
+def fill_waits(L):
+    """LDS operations complete in issue order, so `s_waitcnt lgkmcnt(n)` with n = the number of main-line LDS operations
+    issued after the one that is needed waits for exactly that one.  The main line is the loop body in steady state
+    (poll paths drain everything and only make a later wait trivially true).  A step's WAIT needs the query-offset read
+    (;MQ, issued after the profile read) of two steps before, across units and across the loop's back edge."""
+    main = [(j, ln) for j, ln in enumerate(L) if ln == "WAIT" or ";M" in ln]
+    n = len(main)
+    out = list(L)
+    for pos, (j, ln) in enumerate(main):
+        if ln != "WAIT":
+            continue
+        # walk back (cyclically) to the second ;MQ before this wait
+        seen_q, younger, p = 0, 0, pos
+        while True:
+            p = (p - 1) % n
+            t = main[p][1]
+            if t == "WAIT":
+                continue
+            if t.endswith(";MQ"):
+                seen_q += 1
+                if seen_q == 2:
+                    break
+            younger += 1
+        out[j] = "s_waitcnt lgkmcnt(%d)" % younger
+    return [ln.replace(" ;MQ", "").replace(" ;M", "") for ln in out]
 
 
 def main():
@@ -193,6 +316,17 @@ def main():
                     last = j + 1 == len(lines)
                     f.write('    "%s%s"%s\n' % (ln, "" if last else "\\n\\t", "" if last else " \\"))
                 f.write("\n")
+                if kind != "FIRST":
+                    # the same loop with the cell update under exec = {lanes whose column exists}: the strip's first 64
+                    # steps and its tail (ramp-down + what is left of N after the last full quad).  A strip finishes
+                    # `lag` steps after the strip above it, so the tail is on the critical path of EVERY strip.
+                    lines = loop(R, kind, masked=True)
+                    f.write("// R = %d, %s strip: masked quads (ramp-up / tail)\n" % (R, kind))
+                    f.write("#define ALN_MASKED_ASM_R%d_%s \\\n" % (R, kind))
+                    for j, ln in enumerate(lines):
+                        last = j + 1 == len(lines)
+                        f.write('    "%s%s"%s\n' % (ln, "" if last else "\\n\\t", "" if last else " \\"))
+                    f.write("\n")
     print("wrote", os.path.normpath(out))
 
 
