@@ -448,9 +448,11 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         sa.store_dirs = b->store_dirs ? 1u : 0u;
         sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
         aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), s);
+        // the granule rows must read "not yet produced" before a pass: one memset here, later passes are zeroed by the
+        // finalize kernel that arms them
+        HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 4, s));
         for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
             sa.pass = pass;
-            HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 4, s));
             aln_launch_single(&sa, d.N, pass + 1 == sa.max_passes ? 1 : 0, s);
             b->fill_launches++;
         }

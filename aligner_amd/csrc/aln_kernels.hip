@@ -667,26 +667,19 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     }
 }
 
-// One wave: folds the per-strip candidates, checks the row-1 advice against the bottom row this pass produced and
-// either publishes the result or arms the next pass (ctrl[1 + pass + 1]) / the serial fallback (ctrl[15]).
+// One block of 1024 threads: folds the per-strip candidates, checks the row-1 advice against the bottom row this pass
+// produced and either publishes the result or adopts the observed zeros as the new advice, zeroes the granule rows and
+// arms the next pass (ctrl[1 + pass + 1]) / the serial fallback (ctrl[15]).  (Zeroing here rather than with a memset
+// per pass keeps the launches of the passes that turn out not to be needed down to two early-exit kernels each.)
 template <int SEM>
-__global__ __launch_bounds__(64) void aln_single_finalize_kernel(SingleArgs a)
+__global__ __launch_bounds__(1024) void aln_single_finalize_kernel(SingleArgs a)
 {
     if (__hip_atomic_load(a.ctrl + 1 + a.pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-    const int lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const int lane = (int)(tid & 63u);
     PairDesc &desc = a.descs[a.pair];
     aln_pair_result &res = a.results[a.pair];
     const uint32_t N = desc.N, M = desc.M;
-    FastOut o;
-    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
-    for (uint32_t s = lane; s < a.ns; s += 64) {
-        const int32_t *c = a.cand + 4 * s;
-        if (c[2] != 0 && (o.bx == 0 || better_i<SEM>(c[0], (uint32_t)c[1], (uint32_t)c[2], o.bv, o.by, o.bx))) { o.bv = c[0]; o.by = c[1]; o.bx = c[2]; }
-    }
-    reduce_best<SEM>(o);
-    const int bv = o.bv;
-    const uint32_t by = o.by, bx = o.bx;
-    int mismatch = 0;
     // H[M][x] == 0 <=> the stored tag of cell (M, x) is 3; the last strip recorded the direction words of the lane that
     // owns row M, one per block
     const uint32_t rows_last = M - (a.ns - 1) * 64u * a.R;
@@ -696,21 +689,37 @@ __global__ __launch_bounds__(64) void aln_single_finalize_kernel(SingleArgs a)
         const uint32_t k = x - 1 + lb;
         return ((zdw[k / spb] >> aln_dir_bitpos(k, rb, lb, N, (int)a.R)) & 3u) == 3u ? 1 : 0;
     };
-    if (a.hazard) for (uint32_t x = 2 + lane; x <= N; x += 64) mismatch |= (a.advice[x] != bottom_zero(x - 1));
-    const bool again = __any(mismatch);
+    int mismatch = 0;
+    if (a.hazard) for (uint32_t x = 2 + tid; x <= N; x += blockDim.x) mismatch |= (a.advice[x] != bottom_zero(x - 1));
+    const bool again = __syncthreads_or(mismatch) != 0;
     const bool aborted = a.ctrl[0] != 0;
     if (again && !aborted) {
-        for (uint32_t x = 2 + lane; x <= N; x += 64) a.advice[x] = bottom_zero(x - 1);
-        if (lane == 0) {
+        for (uint32_t x = 2 + tid; x <= N; x += blockDim.x) a.advice[x] = bottom_zero(x - 1);
+        if (a.pass + 1 < a.max_passes) {
+            uint4 *g = reinterpret_cast<uint4 *>(a.granules);       // the next pass needs "not yet produced" everywhere
+            const uint64_t n16 = (uint64_t)a.ns * a.gstride / 4u;   // gstride is a multiple of 64
+            for (uint64_t i = tid; i < n16; i += blockDim.x) g[i] = make_uint4(0, 0, 0, 0);
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
             if (a.pass + 1 < a.max_passes) a.ctrl[1 + a.pass + 1] = 1;
             else a.ctrl[15] = a.pass + 1;               // not self-consistent within the cap: strict-order kernel
         }
         return;
     }
+    if (tid >= 64) return;
+    FastOut o;
+    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
+    for (uint32_t s = lane; s < a.ns; s += 64) {
+        const int32_t *c = a.cand + 4 * s;
+        if (c[2] != 0 && (o.bx == 0 || better_i<SEM>(c[0], (uint32_t)c[1], (uint32_t)c[2], o.bv, o.by, o.bx))) { o.bv = c[0]; o.by = c[1]; o.bx = c[2]; }
+    }
+    reduce_best<SEM>(o);
     if (lane == 0) {
         const int corner = a.cand[4 * (a.ns - 1) + 3] >> 2;
         desc.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
-        write_result<SEM>(res, (double)(bv >> 2), by, bx, (double)corner, N, M, a.pass + 1, 1u | 2u);
+        write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)corner, N, M, a.pass + 1, 1u | 2u);
         if (aborted) res.status = ALN_ERR_DEVICE;
     }
 }
@@ -1263,7 +1272,7 @@ extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_seri
         else if (a->R == 2) ALN_SINGLE_LAUNCH(SEM, 2, 1);                                                      \
         else if (a->R == 4) ALN_SINGLE_LAUNCH(SEM, 4, 1);                                                      \
         else ALN_SINGLE_LAUNCH(SEM, 8, 1);                                                                     \
-        hipLaunchKernelGGL((aln_single_finalize_kernel<SEM>), dim3(1), dim3(64), 0, s, *a);                    \
+        hipLaunchKernelGGL((aln_single_finalize_kernel<SEM>), dim3(1), dim3(1024), 0, s, *a);                    \
         if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<SEM>), dim3(1), dim3(64), serial_lds, s, *a); \
     } while (0)
     switch (a->semantics) {
@@ -1272,7 +1281,7 @@ extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_seri
         if (W == 4) {
             if (a->R == 1) ALN_SINGLE_LAUNCH(ALN_CORE_LOCAL, 1, 4);
             else ALN_SINGLE_LAUNCH(ALN_CORE_LOCAL, 2, 4);
-            hipLaunchKernelGGL((aln_single_finalize_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(64), 0, s, *a);
+            hipLaunchKernelGGL((aln_single_finalize_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(1024), 0, s, *a);
             if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(64), serial_lds, s, *a);
         } else ALN_SINGLE(ALN_CORE_LOCAL);
         break;
