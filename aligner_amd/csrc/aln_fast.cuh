@@ -36,7 +36,11 @@ __device__ __forceinline__ int v_add3_m1(int a, int b)         // a + b - 1
 }
 __device__ __forceinline__ int v_pack11(int t, int kterm)      // (t << 11) + kterm, kterm wave-uniform
 {
-    return (int)(((uint32_t)t << 11) + (uint32_t)kterm);      // the compiler emits v_lshl_add_u32
+    // as asm: left to itself the compiler folds the computation of kterm into every cell (v_lshlrev + v_bitop3 against
+    // the step counter), one VALU instruction more per cell than this
+    int d;
+    asm("v_lshl_add_u32 %0, %1, 11, %2" : "=v"(d) : "v"(t), "s"(kterm));
+    return d;
 }
 // The heart of a cell as ONE statement (hipcc pads every asm statement with a wait state, so one statement per cell,
 // not one per instruction).  pw holds four int8 profile scores; B selects this row's byte:
@@ -160,7 +164,9 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 }
 __device__ __forceinline__ uint64_t uniform64(const void *p) { return uniform64((uint64_t)(uintptr_t)p); }
 
-template <int SEM, int R, bool SINGLE, bool FIRST, bool LAST>
+// PWM (position-weight-matrix scoring, batch kernels only) is a template parameter: a run-time test of it sat in the
+// hot loop of every batch fill.
+template <int SEM, int R, bool SINGLE, bool FIRST, bool LAST, bool PWM = false>
 struct FastStrip {
     static constexpr int SPB = 16 / R;
     static constexpr uint32_t STRIP_ROWS = SINGLE ? 64u * R : (uint32_t)ALN_STRIP_ROWS;
@@ -238,7 +244,7 @@ struct FastStrip {
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
             if (!FIRST && !SINGLE) inchunk = load_boundary(xi);
             if (SEM == ALN_CORE_LOCAL && FIRST && in.hazard) advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
-            if (!SINGLE) qchunk = (xi + 1 < N) ? (in.pwm ? (int)in.pwm_words[xi + 1] : (int)in.q[xi + 1] * (64 * R)) : 0;
+            if (!SINGLE) qchunk = (xi + 1 < N) ? (PWM ? (int)in.pwm_words[xi + 1] : (int)in.q[xi + 1] * (64 * R)) : 0;
         }
         const int sel = (int)(k & 63u);
         int top0;
@@ -256,7 +262,7 @@ struct FastStrip {
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2 * (k + 2));         // step k+2
         } else {
             qoff = shr1_i(__builtin_amdgcn_readlane(qchunk, sel), qoff);             // next step's query code reaches every lane
-            pw = in.pwm ? pwm_select((uint32_t)qoff) : *reinterpret_cast<const PW *>(prow + qoff);
+            if constexpr (PWM) pw = pwm_select((uint32_t)qoff); else pw = *reinterpret_cast<const PW *>(prow + qoff);
         }
         // end-cell tie-break term of this step: earlier steps win (core) / later steps win (legacy)
         const int kterm = (SEM == ALN_CORE_LOCAL) ? (int)(2047u - (k & 2047u)) : (int)(k & 2047u);
@@ -615,7 +621,7 @@ struct FastStrip {
             const uint32_t code = (y <= M) ? (uint32_t)in.t[y - 1] & 3u : 0u;
             if (r < 4) psel_lo |= code << (8 * r); else psel_hi |= code << (8 * (r - 4));
         }
-        for (uint32_t c = 0; c < (in.pwm ? 0u : in.cols); ++c) {
+        for (uint32_t c = 0; c < (PWM ? 0u : in.cols); ++c) {
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -641,9 +647,9 @@ struct FastStrip {
             qoff = *reinterpret_cast<const uint16_t *>(qo_lane);                      // step 0: column -lane
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2);                    // step 1
         } else {
-            qoff = (lane == 0) ? (in.pwm ? (int)in.pwm_words[0] : (int)in.q[0] * (64 * R)) : 0;
+            qoff = (lane == 0) ? (PWM ? (int)in.pwm_words[0] : (int)in.q[0] * (64 * R)) : 0;
         }
-        if (!SINGLE && in.pwm) pw = pwm_select((uint32_t)qoff);
+        if (!SINGLE && PWM) pw = pwm_select((uint32_t)qoff);
         else pw = *reinterpret_cast<const PW *>(prow + qoff);
 
         // directions: four blocks per lane per 16-byte store (aln_device.h); all segment ends are whole quads
@@ -725,25 +731,25 @@ struct FastStrip {
 };
 
 // Batch kernels: every strip but the last has 512 rows (R = 8); the last one picks R by its row count.
-template <int SEM>
+template <int SEM, bool PWM>
 __device__ __forceinline__ FastOut fast_strip(const FastIn &in, FastOut o, uint32_t s, bool last, int R)
 {
     if (!last) {
-        if (s == 0) { FastStrip<SEM, ALN_FULL_R, false, true, false> f(in, s); return f.run(o); }
-        FastStrip<SEM, ALN_FULL_R, false, false, false> f(in, s);
+        if (s == 0) { FastStrip<SEM, ALN_FULL_R, false, true, false, PWM> f(in, s); return f.run(o); }
+        FastStrip<SEM, ALN_FULL_R, false, false, false, PWM> f(in, s);
         return f.run(o);
     }
     if (s == 0) {
-        if (R == 8) { FastStrip<SEM, 8, false, true, true> f(in, s); return f.run(o); }
-        if (R == 4) { FastStrip<SEM, 4, false, true, true> f(in, s); return f.run(o); }
-        if (R == 2) { FastStrip<SEM, 2, false, true, true> f(in, s); return f.run(o); }
-        FastStrip<SEM, 1, false, true, true> f(in, s);
+        if (R == 8) { FastStrip<SEM, 8, false, true, true, PWM> f(in, s); return f.run(o); }
+        if (R == 4) { FastStrip<SEM, 4, false, true, true, PWM> f(in, s); return f.run(o); }
+        if (R == 2) { FastStrip<SEM, 2, false, true, true, PWM> f(in, s); return f.run(o); }
+        FastStrip<SEM, 1, false, true, true, PWM> f(in, s);
         return f.run(o);
     }
-    if (R == 8) { FastStrip<SEM, 8, false, false, true> f(in, s); return f.run(o); }
-    if (R == 4) { FastStrip<SEM, 4, false, false, true> f(in, s); return f.run(o); }
-    if (R == 2) { FastStrip<SEM, 2, false, false, true> f(in, s); return f.run(o); }
-    FastStrip<SEM, 1, false, false, true> f(in, s);
+    if (R == 8) { FastStrip<SEM, 8, false, false, true, PWM> f(in, s); return f.run(o); }
+    if (R == 4) { FastStrip<SEM, 4, false, false, true, PWM> f(in, s); return f.run(o); }
+    if (R == 2) { FastStrip<SEM, 2, false, false, true, PWM> f(in, s); return f.run(o); }
+    FastStrip<SEM, 1, false, false, true, PWM> f(in, s);
     return f.run(o);
 }
 

@@ -427,7 +427,7 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
 // sit next to the left border, so a mismatch is repaired by re-running only the leading columns of strip 0 until its
 // lane state rejoins the checkpoint (localized repair); anything else escalates to full re-fills and finally to the
 // strict reference-order routine.
-template <int SEM>
+template <int SEM, bool PWM>
 __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairDesc &desc, aln_pair_result &res, int del, int ext)
 {
     const int lane = in.lane;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
         for (uint32_t s = 0; s < ns; ++s) {
             const bool last = (s + 1 == ns);
             if (s > 0) __threadfence_block();            // strip s reads the boundary row strip s-1 stored
-            o = fast_strip<SEM>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R);
+            o = fast_strip<SEM, PWM>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R);
         }
         ++passes;
         __threadfence_block();
@@ -475,7 +475,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
                 in.ck_mode = 2; in.last_flip = last_flip;
                 FastOut ro = o;
                 ro.repaired = false; ro.brow_bad = false;
-                ro = fast_strip<SEM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : ALN_FULL_R);
+                ro = fast_strip<SEM, PWM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : ALN_FULL_R);
                 __threadfence_block();
                 if (!__any(ro.repaired) || __any(ro.brow_bad)) break;     // escalate to a full pass
                 if (ns > 1) { converged = true; break; }                  // the bottom strip, hence z, is untouched
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void aln_fill_kernel(FillArgs a)
     }
 }
 
-template <int SEM>
+template <int SEM, bool PWM>
 __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
         PairDesc &desc = a.descs[pair];
         aln_pair_result &res = a.results[pair];
         if (desc.status != ALN_OK) { skip_invalid(res, desc.status, in.lane); continue; }
-        do_pair_fast<SEM>(in, a, desc, res, (int)a.del, (int)a.ext);
+        do_pair_fast<SEM, PWM>(in, a, desc, res, (int)a.del, (int)a.ext);
     }
 }
 
@@ -1217,11 +1217,14 @@ extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_
 {
     const dim3 g(grid), b(256);
 #define ALN_LAUNCH(SC, SEM) hipLaunchKernelGGL((aln_fill_kernel<SC, SEM>), g, b, lds_bytes, s, *a)
-#define ALN_LAUNCH_FAST(SEM) hipLaunchKernelGGL((aln_fill_fast_kernel<SEM>), g, b, lds_bytes, s, *a)
+#define ALN_LAUNCH_FAST(SEM) hipLaunchKernelGGL((aln_fill_fast_kernel<SEM, false>), g, b, lds_bytes, s, *a)
     if (is_int && fast) {
         switch (a->semantics) {
         case ALN_CORE_GLOBAL: ALN_LAUNCH_FAST(ALN_CORE_GLOBAL); break;
-        case ALN_CORE_LOCAL: ALN_LAUNCH_FAST(ALN_CORE_LOCAL); break;
+        case ALN_CORE_LOCAL:
+            if (a->pwm) hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, true>), g, b, lds_bytes, s, *a);
+            else ALN_LAUNCH_FAST(ALN_CORE_LOCAL);
+            break;
         case ALN_LEGACY_GLOBAL: ALN_LAUNCH_FAST(ALN_LEGACY_GLOBAL); break;
         default: ALN_LAUNCH_FAST(ALN_LEGACY_LOCAL); break;
         }
