@@ -895,12 +895,20 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
         }
     } else {
         StripView sv = strip_view(a.dirs, d, cy != 0 ? cy : 1u);
+        // The walk is one dependent load per step, and every miss is a trip to HBM (the direction store is tens of GB).
+        // A lane's quad (4 blocks, 16 B) covers 64/R consecutive steps of R rows: a path that moves up/left stays in
+        // it for several steps, so the last quad is kept in registers and only a change of quad loads.
+        const uint4 *qcur = nullptr;
+        uint4 quad = make_uint4(0, 0, 0, 0);
         while (cy != 0 && cx != 0) {
             if (cy - 1 - sv.y0 >= (64u << sv.lgR)) sv = strip_view(a.dirs, d, cy);   // the walk left the strip (upwards)
             const uint32_t i = cy - 1 - sv.y0, lgR = sv.lgR, R = 1u << lgR, sh = 4u - lgR;
             const uint32_t lane = i >> lgR, r = i & (R - 1u);
             const uint32_t k = cx - 1 + lane, kb = k >> sh;
-            const uint32_t word = sv.wbase[(((uint64_t)(kb >> 2) * 64u + lane) << 2) + (kb & 3u)];
+            const uint4 *qp = reinterpret_cast<const uint4 *>(sv.wbase) + ((uint64_t)(kb >> 2) * 64u + lane);
+            if (qp != qcur) { quad = *qp; qcur = qp; }
+            const uint32_t sel = kb & 3u;
+            const uint32_t word = sel == 0 ? quad.x : sel == 1 ? quad.y : sel == 2 ? quad.z : quad.w;
             const uint32_t bend = (kb << sh) + (1u << sh) - 1u, lend = lane + N - 1u;
             const uint32_t e = min(bend, lend);
             const uint32_t tag = (word >> (30u - 2u * (((e - k) << lgR) + (R - 1u - r)))) & 3u;
