@@ -210,32 +210,8 @@ struct FastStrip {
         else return (PW)__builtin_amdgcn_perm(w4, w4, psel_lo);
     }
 
-    // next 64 columns of the row above this strip (T form), one per lane
-    __device__ __forceinline__ int load_boundary(uint32_t xi)
-    {
-        if constexpr (!SINGLE) {
-            return (xi < N) ? in.brow[xi + 1] : 2;
-        } else {
-            const uint32_t *src = in.gin + xi;
-            uint32_t g = 0;
-            uint32_t spins = 0;
-            for (;;) {
-                const bool need = xi < N;
-                if (need) g = granule_load(src);
-                if (__all(!need || g != 0)) break;
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-                if (spins > (1u << 22) ||
-                    ((spins & 1023u) == 0 && __hip_atomic_load(in.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    // the producer never arrived: poison the run instead of hanging the GPU
-                    if (lane == 0) __hip_atomic_store(in.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    aborted = true;
-                    break;
-                }
-            }
-            return (xi < N) ? (int)g : 2;
-        }
-    }
+    // batch kernels: next 64 columns of the row above this strip (T form), one per lane
+    __device__ __forceinline__ int load_boundary(uint32_t xi) { return (xi < N) ? in.brow[xi + 1] : 2; }
 
     template <bool MASKED>
     __device__ __forceinline__ void step(const uint32_t k)

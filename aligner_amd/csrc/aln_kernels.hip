@@ -793,50 +793,6 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
     return aln_tag_to_dir((int)((word >> aln_dir_bitpos(k, r, lane, d.N, R)) & 3u));
 }
 
-// Touches the direction words the next ~16 traceback steps will need (the path moves up/left: blocks kb, kb-1, ...
-// of the current lane and of the lanes just above it).  The walk is one dependent load per step; loads return in
-// order, so the look-ahead is issued as ONE burst of independent loads (one HBM round trip) after which the next
-// ~16 demand loads hit L1/L2.  Returns a value derived from the loaded words so that the loads stay live.
-__device__ __forceinline__ uint32_t dir_prefetch(const uint8_t *dirs, const PairDesc &d, uint32_t y, uint32_t x)
-{
-    if (y == 0 || x == 0 || d.layout == ALN_LAYOUT_ROWMAJOR) return 0;
-    const uint8_t *base = dirs + d.dir_off;
-    uint32_t strip, i;
-    int R;
-    uint64_t strip_bytes;
-    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) {
-        R = (int)((d.layout >> 8) & 0xffu);
-        strip = (y - 1) / (64u * R);
-        i = (y - 1) - strip * 64u * R;
-        strip_bytes = aln_uniform_strip_bytes(d.N, (uint32_t)R);
-    } else {
-        strip = (y - 1) / ALN_STRIP_ROWS;
-        const uint32_t ns = aln_num_strips(d.M);
-        R = (strip + 1 == ns) ? aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : ALN_FULL_R;
-        i = (y - 1) - strip * ALN_STRIP_ROWS;
-        strip_bytes = aln_strip_bytes(d.N);
-    }
-    const uint32_t lane = i / R, spb = 16u / R;
-    const uint32_t kb = ((x - 1) + lane) / spb;
-    const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * strip_bytes);
-    // a quad (4 blocks x 16 B) per lane, 8 lanes per 128-byte line: touch the current and the next two quads of
-    // this lane's line and of the line above it
-    const uint32_t kq = kb >> 2;
-    uint32_t v[18];
-#pragma unroll
-    for (uint32_t j = 0; j < 9; ++j) {
-        const uint32_t jj = j % 3, up = j / 3;
-        const uint32_t b = kq >= jj ? kq - jj : 0;
-        const uint32_t la = lane >= up * 8 ? lane - up * 8 : 0;
-        v[2 * j] = wbase[((uint64_t)b * 64 + la) * 4];
-        v[2 * j + 1] = wbase[((uint64_t)b * 64 + la) * 4 + 3];
-    }
-    uint32_t acc = 0;
-#pragma unroll
-    for (int j = 0; j < 18; ++j) acc |= v[j];
-    return acc;
-}
-
 // Per-strip constants of the packed direction store, re-derived only when the walk leaves the strip.
 struct StripView {
     const uint32_t *wbase;
@@ -876,8 +832,6 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     aln_pair_result &res = a.results[pair];
     if (res.status != ALN_OK) return;
     if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) return;      // large pairs: aln_tb_single_* kernels
-    const uint8_t *__restrict__ q = a.seqs + d.q_off;
-    const uint8_t *__restrict__ t = a.seqs + d.t_off;
     const uint32_t cap = d.N + d.M + 2;
     uint8_t *__restrict__ ops = a.tb + d.tb_off + (a.pwm ? 5ull : 2ull) * cap;
     const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);

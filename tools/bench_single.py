@@ -1,3 +1,5 @@
+"""One large pair (default 10 000 x 10 000, C4) through the single-pair route: fill / traceback times from the
+library's HIP events.  usage: python tools/bench_single.py [N [M]]   (env ALN_SINGLE_R, ALN_SINGLE_W1 select variants)"""
 import sys, time, numpy as np
 sys.path.insert(0,'.')
 import torch

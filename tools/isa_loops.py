@@ -1,3 +1,5 @@
+"""Loop statistics of one kernel in a `hipcc -S` listing (instruction classes per back edge): python tools/isa_loops.py
+k.s <line of the kernel label>.  Used to count the instructions of the fill kernels' steady-state loops."""
 import re,sys
 lines=open(sys.argv[1]).read().split('\n')
 start=int(sys.argv[2]); 

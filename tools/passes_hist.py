@@ -1,3 +1,4 @@
+"""Histogram of aln_pair_result.passes over a C5 sample: how many pairs took the row-1 repair / a second full pass."""
 import sys, numpy as np
 sys.path.insert(0,'.')
 from aligner_amd import _ffi, workloads
