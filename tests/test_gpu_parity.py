@@ -487,11 +487,13 @@ def test_heuristic_pwm_aligner_loop_matches_oracle_loop(orc):
 
 # ---------------------------------------------------------------- single-pair kernel (one wave per strip, asm steady state)
 @pytest.mark.parametrize("r", ["1", "2"])
-@pytest.mark.parametrize("shape", [(500, 700), (1000, 300), (2100, 130), (777, 1031), (2500, 200), (4200, 129)])
+@pytest.mark.parametrize("shape", [(500, 700), (1000, 300), (2100, 130), (777, 1031), (2500, 200), (4200, 129), (64, 4200), (130, 2100),
+                                   (95, 2800)])
 def test_single_pair_kernel_forced_rows_per_lane(orc, blosum62, monkeypatch, r, shape):
     """The strip-pipelined kernel with its hand-scheduled steady-state loop (tools/gen_single_asm.py), R = 1 and R = 2 rows
     per lane forced through ALN_SINGLE_R: every direction of the matrix, end cell, coordinates and both strings.
-    Shapes: ragged last strips, N not a multiple of 64, N across the 2048-step tracker boundary; zero-rich +-1 scoring
+    Shapes: ragged last strips, N not a multiple of 64, N across the 2048-step tracker boundary and the 4096-column LDS
+    ring, N too short for a single unmasked quad (every quad runs the masked loop); zero-rich +-1 scoring
     makes the row-1 hazard bite (several passes, strip 0 switching between the asm loop and the C++ step)."""
     monkeypatch.setenv("ALN_SINGLE_R", r)
     N, M = shape
@@ -503,6 +505,6 @@ def test_single_pair_kernel_forced_rows_per_lane(orc, blosum62, monkeypatch, r, 
         res = check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S4, directions_only=True)
         assert res.flags & 2, "expected the single-pair route"
     qp = rng.integers(0, 20, N).astype(np.uint8)
-    tp = np.concatenate([rng.integers(0, 20, M // 3).astype(np.uint8), qp[N // 4:N // 4 + M - M // 3]])[:M]
+    tp = np.concatenate([rng.integers(0, 20, M // 3).astype(np.uint8), np.tile(qp, M // N + 2)[N // 4:N // 4 + M - M // 3]])[:M]
     res = check_pair(orc, _ffi.CORE_LOCAL, qp, tp, 11, 2, blosum62, directions_only=True)
     assert res.flags & 2
