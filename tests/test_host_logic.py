@@ -153,3 +153,27 @@ def test_transform_matrix_properties(blosum62):
     with pytest.raises(Exception) as e:        # |k_d| > sqrt(r^2 * sum p^2): no real root -> Err(WrongMatrixSpecified)
         transform_matrix(blosum62, -1.5, r2, freqs)
     assert type(e.value).__name__ == "WrongMatrixSpecified"
+
+
+def test_generated_asm_is_in_sync_with_its_generator(tmp_path):
+    """aligner_amd/csrc/aln_single_unit.inc is generated by tools/gen_single_asm.py and committed: regenerate and compare;
+    and check the invariants the kernel relies on: every in-loop LDS wait is an explicit count, the loop drains before it
+    ends, and each variant names its poll loops uniquely."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_single_asm", os.path.join(ROOT, "tools", "gen_single_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(ROOT, "aligner_amd", "csrc", "aln_single_unit.inc")).read()
+    for R in (1, 2):
+        for kind in ("FIRST", "MID", "LAST"):
+            for masked in ((False,) if kind == "FIRST" else (False, True)):
+                lines = gen.loop(R, kind, masked)
+                assert "WAIT" not in lines and not any(";M" in ln for ln in lines)
+                assert lines[-1] == "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                labels = [ln for ln in lines if ln.endswith(":")]
+                assert len(labels) == len(set(labels))
+                name = "ALN_%s_ASM_R%d_%s" % ("MASKED" if masked else "STEADY", R, kind)
+                body = committed[committed.index("#define " + name):]
+                body = body[:body.index("\n\n")]
+                got = [ln.strip().rstrip("\\").strip().strip('"').replace("\\n\\t", "") for ln in body.splitlines()[1:]]
+                assert got == lines, name
