@@ -150,14 +150,15 @@ def main():
         fill_s = timing["fill_ms"] / 1e3
         alg_bytes = ALG_BYTES_PER_CELL * batch.cells + float((batch.q_len + batch.t_len).sum()) + 48.0 * len(batch)
         achieved = alg_bytes / fill_s / 1e9
-        traffic = None
+        traffic = valu_insts = None
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
             key = "c5_%d_n%d" % (args.pairs, world)
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            valu_insts = tj.get(key, {}).get("valu_wave_insts_per_launch")
         except Exception:
-            traffic = None
+            traffic = valu_insts = None
         line = {
             "metric": "GCUPS (DP cell updates/s), fill + traceback, bit-exact vs CPU ref",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -174,7 +175,10 @@ def main():
                          "traceback_ms": round(timing["traceback_ms"], 4),
                          "fill_only_gcups_rank0": round(batch.cells / fill_s / 1e9, 3),
                          "direction_bytes_stored": sb.direction_bytes,
-                         "valu_frac": round(batch.cells / fill_s * 16 / 78.6e12, 5)},
+                         "valu_frac": round(batch.cells / fill_s * 16 / 78.6e12, 5),
+                         # the binding roof: VALU issue.  PMC-counted wave instructions per launch / kernel time over the
+                         # chip's 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 int32 instruction
+                         "valu_issue_frac": (round(valu_insts / fill_s / 614.4e9, 4) if valu_insts else None)},
             # never `value`: the same job when the boundary hands over HOST buffers (one staging + one step + one fetch)
             "pcie_inclusive": {"stage_ms": round(t_stage * 1e3, 2), "fetch_ms": round(t_fetch * 1e3, 2),
                                "gcups_rank0": round(batch.cells / (t_stage + elapsed / args.steps + t_fetch) / 1e9, 2)},
