@@ -508,3 +508,20 @@ def test_single_pair_kernel_forced_rows_per_lane(orc, blosum62, monkeypatch, r, 
     tp = np.concatenate([rng.integers(0, 20, M // 3).astype(np.uint8), np.tile(qp, M // N + 2)[N // 4:N // 4 + M - M // 3]])[:M]
     res = check_pair(orc, _ffi.CORE_LOCAL, qp, tp, 11, 2, blosum62, directions_only=True)
     assert res.flags & 2
+
+
+@pytest.mark.parametrize("r", ["1", "2"])
+def test_single_pair_kernel_one_strip_per_workgroup(orc, blosum62, monkeypatch, r):
+    """The same kernel with one wave per workgroup (every hand-off through the granule rows) -- the configuration used
+    when the query is too long for four strips' LDS; forced here through ALN_SINGLE_W1."""
+    monkeypatch.setenv("ALN_SINGLE_R", r)
+    monkeypatch.setenv("ALN_SINGLE_W1", "1")
+    rng = np.random.default_rng(77)
+    for N, M in ((777, 1031), (2500, 200)):
+        q = rng.integers(0, 4, N).astype(np.uint8)
+        t = rng.integers(0, 4, M).astype(np.uint8)
+        res = check_pair(orc, _ffi.CORE_LOCAL, q, t, 2, 1, np.where(np.eye(4) > 0, 1.0, -1.0), directions_only=True)
+        assert res.flags & 2
+        qp = rng.integers(0, 20, N).astype(np.uint8)
+        tp = np.concatenate([rng.integers(0, 20, M // 3).astype(np.uint8), np.tile(qp, M // N + 2)[N // 4:N // 4 + M - M // 3]])[:M]
+        assert check_pair(orc, _ffi.CORE_LOCAL, qp, tp, 11, 2, blosum62, directions_only=True).flags & 2
