@@ -67,6 +67,7 @@ struct FillArgs {
     const uint32_t *pwm_words;// fast path: per column the four int8 scores 4*s - 2 of residues 0..3, packed
     uint32_t no_repair;       // 1: disable the localized strip-0 repair (testing: full re-fills only)
     uint32_t ck_bytes;        // fast path: bytes of the checkpoint + strip-0 bottom-row areas in each wave's scratch
+    uint32_t zrow_bytes;      // bytes of the bottom-row record in each wave's scratch (bytes per column, or one direction word per block)
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
     uint8_t blank;
 };

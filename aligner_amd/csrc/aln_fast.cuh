@@ -143,6 +143,7 @@ struct FastOut {
     uint32_t by, bx;
     int corner;
     bool repaired, brow_bad, aborted;
+    uint32_t ck_slot;         // repair pass: checkpoint (0 = step 64, 1 = 128, 2 = 256, 3 = 512) at which the lane state re-converged
 };
 
 // a better-than-b for the local end cell, values in any monotone form
@@ -293,12 +294,6 @@ struct FastStrip {
                     if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 1) in.brow0[x] = bottom;
                 }
             }
-            if (SEM == ALN_CORE_LOCAL && !SINGLE && zsel_on && (uint32_t)lane == lb) {
-                int hb = Tl[0];
-#pragma unroll
-                for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Tl[r];
-                in.zrow[xm1 + 1] = (hb == 2) ? 1 : 0;
-            }
         }
         // bottom row to the strip below: lane 63's newest cell enters a 64-deep lane shift register (DPP wave_shl:1)
         if (SINGLE && !LAST) outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);
@@ -371,11 +366,11 @@ struct FastStrip {
 
     // four blocks of SPB steps -> one 16-byte store per lane (1 KiB per wave, coalesced).  The block loop is a real
     // loop (not unrolled): unrolling 4*SPB steps makes the scheduler hoist every step's uniform values and spill.
-    // the single-pair kernel's bottom-row zero flags travel as the direction words of the lane that owns row M (tag 3 =
-    // Beginning <=> H == 0): one dword per block instead of one byte store per step
+    // the bottom-row zero flags (row-1 hazard) travel as the direction words of the lane that owns row M (tag 3 =
+    // Beginning <=> H == 0): one dword per block instead of a select chain and a byte store per step
     __device__ __forceinline__ void store_zdw(uint32_t block)
     {
-        if (SINGLE && SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) reinterpret_cast<uint32_t *>(in.zrow)[block] = dw;
+        if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) reinterpret_cast<uint32_t *>(in.zrow)[block] = dw;
     }
 
     // ---- steady state of the single-pair core-local kernel (ASMPATH): whole quads through the generated asm loop.
@@ -683,6 +678,7 @@ struct FastStrip {
                     // every lane is in exactly the state the checkpointed pass had here and no advice differs from
                     // here on: the rest of this strip -- and so of the whole fill -- is unchanged
                     o.repaired = true;
+                    o.ck_slot = slot;
                     o.brow_bad = o.brow_bad || brow_bad;
                     return o;
                 }

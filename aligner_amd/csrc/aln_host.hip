@@ -66,6 +66,7 @@ struct aln_batch {
     uint32_t max_len = 0;
     uint32_t grid = 0;
     uint64_t scratch_stride = 0;
+    uint32_t zrow_bytes = 0;
     uint32_t lds_bytes = 0;
     std::vector<PairDesc> descs;
     // device
@@ -325,7 +326,11 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
     // + 4 checkpoints of strip 0's lane state (26 ints x 64 lanes) and a copy of strip 0's bottom row (fast path)
     const uint64_t ck_bytes = b->fast ? (4ull * 18 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
-    b->scratch_stride = brow_bytes + 2 * adv_bytes + ck_bytes;
+    // bottom-row record: one byte per column (generic kernels) or one direction dword per block of the last strip (fast
+    // path: at most (max_len + 63) / 2 + 4 blocks)
+    const uint64_t zrow_bytes = std::max<uint64_t>(adv_bytes, (4ull * (((uint64_t)max_len + 63) / 2 + 8) + 63) & ~63ull);
+    b->zrow_bytes = (uint32_t)zrow_bytes;
+    b->scratch_stride = brow_bytes + adv_bytes + zrow_bytes + ck_bytes;
     b->lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
     if (b->fast && !pwm) { b->prof_stride = cols * 64u * ALN_FULL_R; b->lds_bytes += 4u * b->prof_stride; }
 
@@ -416,7 +421,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     FillArgs fa{};
     fa.seqs = b->d_seqs; fa.descs = b->d_descs; fa.order = b->d_order; fa.n_pairs = (uint32_t)b->n_small;
     fa.counter = b->d_counter; fa.dirs = b->d_dirs; fa.results = b->d_results;
-    fa.scratch = b->d_scratch; fa.scratch_stride = b->scratch_stride; fa.max_len = b->max_len;
+    fa.scratch = b->d_scratch; fa.scratch_stride = b->scratch_stride; fa.max_len = b->max_len; fa.zrow_bytes = b->zrow_bytes;
     fa.matrix = b->d_matrix; fa.rows = b->params.rows; fa.cols = b->params.cols; fa.prof_stride = b->prof_stride;
     fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
     fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;

@@ -321,6 +321,28 @@ __device__ __forceinline__ bool adopt_advice(uint8_t *advice, const uint8_t *zro
     return !__any(mismatch);
 }
 
+// the same for the fast path, whose last strip records the direction words of the lane that owns row M (one per block):
+// H[M][x] == 0 <=> tag 3
+__device__ __forceinline__ bool adopt_advice_zdw(uint8_t *advice, const uint32_t *zdw, uint32_t N, uint32_t M, int lane,
+                                                 uint32_t &last_flip)
+{
+    const uint32_t ns = aln_num_strips(M), rows_last = M - (ns - 1) * ALN_STRIP_ROWS;
+    const uint32_t R = (uint32_t)aln_pick_r(rows_last), lb = (rows_last - 1) / R, rb = (rows_last - 1) % R, spb = 16u / R;
+    int mismatch = 0;
+    uint32_t lf = 0;
+    for (uint32_t x = 2 + lane; x <= N; x += 64) {
+        const uint32_t k = x - 2 + lb;                                  // wave step of cell (M, x - 1)
+        const uint8_t z = ((zdw[k / spb] >> aln_dir_bitpos(k, rb, lb, N, (int)R)) & 3u) == 3u ? 1 : 0;
+        if (advice[x] != z) { mismatch = 1; advice[x] = z; }
+        if (z != 0) lf = x;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) lf = max(lf, (uint32_t)__shfl_xor((int)lf, m));
+    last_flip = lf;
+    __threadfence_block();
+    return !__any(mismatch);
+}
+
 // writes the fill-side half of the pair's summary (the traceback kernel adds start cell and length)
 template <int SEM>
 __device__ __forceinline__ void write_result(aln_pair_result &res, double best, uint32_t by, uint32_t bx, double corner,
@@ -444,7 +466,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     in.pwm = a.pwm != 0;
     in.pwm_words = a.pwm_words;
     if (in.hazard)
-        for (uint32_t x = lane; x <= N + 1; x += 64) { in.advice[x] = 0; in.zrow[x] = 0; }
+        for (uint32_t x = lane; x <= N + 1; x += 64) in.advice[x] = 0;      // the bottom-row record is rewritten by every pass
     __threadfence_block();
 
     const uint32_t ns = aln_num_strips(M);
@@ -454,7 +476,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     bool converged = false;
     FastOut o;
     for (;;) {                                           // full passes
-        o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
+        o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0;
         in.ck_mode = (passes == 0 && can_repair) ? 1 : 0;
         for (uint32_t s = 0; s < ns; ++s) {
             const bool last = (s + 1 == ns);
@@ -465,7 +487,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
         __threadfence_block();
         if (!in.hazard) { converged = true; break; }
         uint32_t last_flip = 0;
-        converged = adopt_advice(in.advice, in.zrow, N, lane, last_flip);
+        converged = adopt_advice_zdw(in.advice, reinterpret_cast<const uint32_t *>(in.zrow), N, M, lane, last_flip);
         if (converged) break;
         if (passes == 1 && can_repair) {
             uint32_t repairs = 0;
@@ -478,8 +500,9 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
                 ro = fast_strip<SEM, PWM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : ALN_FULL_R);
                 __threadfence_block();
                 if (!__any(ro.repaired) || __any(ro.brow_bad)) break;     // escalate to a full pass
+                passes = (passes & ~0xf0000u) | ((ro.ck_slot + 1u) << 16);  // diagnostics: where the repair re-converged
                 if (ns > 1) { converged = true; break; }                  // the bottom strip, hence z, is untouched
-                converged = adopt_advice(in.advice, in.zrow, N, lane, last_flip);   // single strip: z may have moved
+                converged = adopt_advice_zdw(in.advice, reinterpret_cast<const uint32_t *>(in.zrow), N, M, lane, last_flip);   // single strip: z may have moved
             }
             if (converged) break;
         }
@@ -542,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void aln_fill_kernel(FillArgs a)
     const uint64_t adv_bytes = ((uint64_t)a.max_len + 66 + 63) & ~(uint64_t)63;
     w.brow = reinterpret_cast<SC *>(sc);
     w.advice = sc + brow_bytes;
-    w.zrow = sc + brow_bytes + adv_bytes;
+    w.zrow = sc + brow_bytes + adv_bytes;                 // a.zrow_bytes >= adv_bytes
     w.S = S;
     w.cols = a.cols;
     w.del = ScOps<SC>::from_double(a.del);
@@ -574,7 +597,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
     in.brow = reinterpret_cast<int *>(sc);
     in.advice = sc + brow_bytes;
     in.zrow = sc + brow_bytes + adv_bytes;
-    in.ckpt = reinterpret_cast<int *>(sc + brow_bytes + 2 * adv_bytes);
+    in.ckpt = reinterpret_cast<int *>(sc + brow_bytes + adv_bytes + a.zrow_bytes);
     in.brow0 = in.ckpt + 4 * 18 * 64;
     in.S = S;
     in.cols = a.cols;
@@ -650,7 +673,7 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     in.ring_out = (W > 1 && wave + 1 < W && !last) ? reinterpret_cast<uint32_t *>(smem + wave * RING_BYTES) : nullptr;
     in.abort_flag = a.ctrl;
     FastOut o;
-    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
+    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0;
     in.qo_pad = qo_pad;
     in.bring = reinterpret_cast<int *>(in.prof + prof_bytes);
     if (strip == 0) {
@@ -710,7 +733,7 @@ __global__ __launch_bounds__(1024) void aln_single_finalize_kernel(SingleArgs a)
     }
     if (tid >= 64) return;
     FastOut o;
-    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false;
+    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0;
     for (uint32_t s = lane; s < a.ns; s += 64) {
         const int32_t *c = a.cand + 4 * s;
         if (c[2] != 0 && (o.bx == 0 || better_i<SEM>(c[0], (uint32_t)c[1], (uint32_t)c[2], o.bv, o.by, o.bx))) { o.bv = c[0]; o.by = c[1]; o.bx = c[2]; }

@@ -84,7 +84,8 @@ typedef struct aln_pair_result {
     uint32_t start_y, start_x;  /* cell where the traceback loop stopped */
     uint32_t aln_len;           /* length of both aligned strings (includes the reference's duplicated seed pair) */
     int32_t status;             /* enum aln_status for this pair */
-    uint32_t passes;            /* speculative fill passes used (1 unless CORE_LOCAL with del != ext); 0x80|n = serial fallback */
+    uint32_t passes;            /* bits 0-6: full fill passes (1 unless CORE_LOCAL with del != ext); bit 7: strict-order fallback;
+                                   bits 8-15: localized repairs of strip 0; bits 16-19: 1 + checkpoint at which the last one re-converged */
     uint32_t flags;             /* bit0: integer kernels were used; bit1: the strip-pipelined single-pair route */
 } aln_pair_result;
 
