@@ -246,11 +246,16 @@ struct FastStrip {
         const uint32_t xm1 = k - (uint32_t)lane;
         if (!MASKED || xm1 < N) {
             int top = topIn, diag = hdiag;
-            bool zr = (topIn == 2);                             // "cell above is Beginning" -> penalty del
-            if (SEM == ALN_CORE_LOCAL && FIRST && lane == 0) {
-                // row 1: the carried penalty comes from the bottom cell of the previous column (advice)
-                zr = (k == 0) || (adv != 0);
+            // "cell above is Beginning" -> penalty del.  Row 1 (lane 0 of strip 0) sits under the border, T = 2 always:
+            // its carried penalty comes from the bottom cell of the previous column instead (the advice), so lane 0
+            // compares against 2 when the advice says "zero" and against a value no T takes when it does not -- one
+            // v_writelane instead of a select chain
+            int cmpv = 2;
+            if (SEM == ALN_CORE_LOCAL && FIRST) {
+                const int l0 = __builtin_amdgcn_readfirstlane(((k == 0) || (adv != 0)) ? 2 : 1);   // wave-uniform, in an SGPR
+                asm("v_writelane_b32 %0, %1, 0" : "+v"(cmpv) : "s"(l0));
             }
+            bool zr = (topIn == cmpv);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 int negp;
