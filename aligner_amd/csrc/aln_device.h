@@ -93,6 +93,10 @@ struct SingleArgs {
     uint32_t store_dirs;
 };
 
+// strip 0 of a hazard pair checkpoints its lane state at steps max(16, one quad), then doubling, up to 512
+#define ALN_CK_SLOTS 6
+#define ALN_CK_FIRST 16u
+
 struct TraceArgs {
     const uint8_t *seqs;
     const PairDesc *descs;

@@ -143,7 +143,7 @@ struct FastOut {
     uint32_t by, bx;
     int corner;
     bool repaired, brow_bad, aborted;
-    uint32_t ck_slot;         // repair pass: checkpoint (0 = step 64, 1 = 128, 2 = 256, 3 = 512) at which the lane state re-converged
+    uint32_t ck_slot;         // repair pass: index of the checkpoint (step 16, 32, 64, ... 512 for R = 8) at which the lane state re-converged
 };
 
 // a better-than-b for the local end cell, values in any monotone form
@@ -638,7 +638,8 @@ struct FastStrip {
         // Segment ends: the 2048-step chunks of the end-cell tracker and, for strip 0 of a hazard pair, the
         // checkpoint steps 64, 128, 256, 512.
         const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0;
-        uint32_t next_ck = ckmode ? 64u : 0xffffffffu, slot = 0, chunk_base = 0;
+        // checkpoints sit on quad boundaries: the first at max(16, one quad of 4 * SPB steps), then doubling up to 512
+        uint32_t next_ck = ckmode ? max(ALN_CK_FIRST, 4u * (uint32_t)SPB) : 0xffffffffu, slot = 0, chunk_base = 0;
         uint32_t kb = 0;
         while (kb < nkb) {
             uint32_t seg_end = min(nkb, (chunk_base + 2048u) / SPB);

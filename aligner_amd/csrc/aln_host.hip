@@ -325,7 +325,7 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
     // + 4 checkpoints of strip 0's lane state (26 ints x 64 lanes) and a copy of strip 0's bottom row (fast path)
-    const uint64_t ck_bytes = b->fast ? (4ull * 18 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
+    const uint64_t ck_bytes = b->fast ? ((uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
     // bottom-row record: one byte per column (generic kernels) or one direction dword per block of the last strip (fast
     // path: at most (max_len + 63) / 2 + 4 blocks)
     const uint64_t zrow_bytes = std::max<uint64_t>(adv_bytes, (4ull * (((uint64_t)max_len + 63) / 2 + 8) + 63) & ~63ull);

@@ -491,7 +491,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
         if (converged) break;
         if (passes == 1 && can_repair) {
             uint32_t repairs = 0;
-            while (!converged && repairs < 8 && last_flip <= 512) {
+            while (!converged && repairs < 8 && last_flip <= 512) {     // 512 = the last checkpoint
                 ++repairs;
                 passes += 0x100u;                        // repairs are counted in bits 8..15
                 in.ck_mode = 2; in.last_flip = last_flip;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
     in.advice = sc + brow_bytes;
     in.zrow = sc + brow_bytes + adv_bytes;
     in.ckpt = reinterpret_cast<int *>(sc + brow_bytes + adv_bytes + a.zrow_bytes);
-    in.brow0 = in.ckpt + 4 * 18 * 64;
+    in.brow0 = in.ckpt + ALN_CK_SLOTS * 18 * 64;
     in.S = S;
     in.cols = a.cols;
     in.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u) + (threadIdx.x >> 6) * a.prof_stride;
