@@ -520,7 +520,9 @@ struct FastStrip {
         uint4 v = make_uint4(0, 0, 0, 0);
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t k0 = (kb + j) * SPB;
+            // wave-uniform by construction; say so (in strip 0 of a hazard pair the compiler otherwise carries the step
+            // counter in a VGPR and pays for it in every step)
+            const uint32_t k0 = FIRST ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((kb + j) * SPB)) : (kb + j) * SPB;
             if (SINGLE && !FIRST && ((k0 + SPB) & 15u) == 0) stage_boundary16((k0 + SPB) >> 4);   // one block ahead
 #pragma unroll
             for (int kk = 0; kk < SPB; ++kk) step<MASKED>(k0 + kk);
