@@ -9,10 +9,13 @@
 // Substitution scores come from a per-strip query profile in LDS, P[c][row] = 4*S[t[row]][c] - 2 as int8, row-contiguous
 // per code: one ds_read of R bytes per step feeds the lane's R cells (SDWA byte adds), conflict-free by construction.
 // The query code flows down the lanes with the same DPP wave_shr:1 that carries the boundary cell.
-// Local end cell: per row one packed register  (T' << 11) | f(step)  updated with ONE v_max per cell, folded every 2048
-// steps with the exact tie rule (first in row-major order: core; last in column-major order: legacy).
-// Per cell (core local): v_cmp, v_cndmask (penalty), v_add, v_add3, v_add_sdwa, v_max3, v_and_or, v_cndmask (tag 3),
-// v_alignbit, v_lshl_add, v_max = 11 VALU ops; core global / legacy global: 6.
+// Local end cell: per row one packed register  (T' << 11) | f(step)  updated with one v_lshl_add per cell and one v_max3
+// per two steps, folded every 2048 steps with the exact tie rule (first in row-major order: core; last in column-major
+// order: legacy).
+// Per cell (core local): v_cmp, v_cndmask (penalty), v_add, v_add3, v_add_sdwa, v_max3, v_and_or, v_max_u32 (tag 3),
+// v_alignbit, v_lshl_add, half a v_max3 = 10.5 VALU instructions; core global / legacy global: 6.
+// Two kernels use this file: the batch kernel (one wave per pair, strips in sequence, C++ step below) and the single-pair
+// kernel (one wave per strip; its steady state is the generated asm of aln_single_unit.inc, see steady_run).
 #pragma once
 
 // ---- single instructions the compiler would otherwise re-associate into longer sequences

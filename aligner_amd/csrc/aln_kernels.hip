@@ -12,8 +12,10 @@
 //     cross-lane traffic per step is ONE DPP wave_shr:1 (lane l-1's bottom cell -> lane l's top input);
 //   * strip s+1 consumes the bottom row of strip s through a per-wave boundary row (HBM/L2 resident, read in
 //     64-column chunks and fed to lane 0 with v_readlane);
-//   * 2-bit directions are packed 16 per lane-register and stored 256 B per wave per block of steps (coalesced);
-//   * the local end cell is tracked per row in registers and reduced with DPP/shuffles at the end.
+//   * 2-bit directions are packed 16 per lane-register; four such blocks of a lane form a 16-byte quad and a wave stores
+//     1 KiB contiguous per quad (aln_device.h);
+//   * the local end cell is tracked per row in registers and reduced with DPP/shuffles at the end;
+//   * one large pair instead runs one wave per strip, four strips per workgroup, pipelined (aln_fill_single_kernel).
 // No MFMA: this is integer (or exact f64) max-plus DP.
 #include <hip/hip_runtime.h>
 #include <float.h>
