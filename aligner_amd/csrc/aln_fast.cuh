@@ -696,7 +696,10 @@ struct FastStrip {
                 ++slot;
                 next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
             }
-            if (LOCAL && kb * SPB == chunk_base + 2048u) { fold(o, chunk_base); chunk_base += 2048u; }
+            if (kb * SPB == chunk_base + 2048u) {         // every semantics advances the chunk; only the local ones track an end cell
+                if (LOCAL) fold(o, chunk_base);
+                chunk_base += 2048u;
+            }
         }
         if (SINGLE && !LAST && !(ASMPATH && !FIRST)) publish(nkb * SPB - 1);     // the last (up to 15) columns (the asm publishes after every unit)
         o.brow_bad = o.brow_bad || brow_bad;

@@ -525,3 +525,17 @@ def test_single_pair_kernel_one_strip_per_workgroup(orc, blosum62, monkeypatch, 
         qp = rng.integers(0, 20, N).astype(np.uint8)
         tp = np.concatenate([rng.integers(0, 20, M // 3).astype(np.uint8), np.tile(qp, M // N + 2)[N // 4:N // 4 + M - M // 3]])[:M]
         assert check_pair(orc, _ffi.CORE_LOCAL, qp, tp, 11, 2, blosum62, directions_only=True).flags & 2
+
+
+@pytest.mark.parametrize("sem", SEMS)
+@pytest.mark.parametrize("shape", [(2500, 100), (2498, 938), (4200, 70)])
+def test_queries_longer_than_one_tracker_chunk(orc, blosum62, sem, shape):
+    """N + 63 > 2048 wave steps: the fill is cut into 2048-step chunks (the local end-cell tracker is folded there).  The
+    non-local semantics once never left the first chunk (an endless loop in the kernel) -- found by tools/fuzz_parity.py.
+    Both routes: (2500, 100) and (4200, 70) go to the batch kernel, (2498, 938) to the single-pair kernel."""
+    N, M = shape
+    rng = np.random.default_rng(N + M + sem)
+    q = rng.integers(0, 20, N).astype(np.uint8)
+    t = rng.integers(0, 20, M).astype(np.uint8)
+    gaps = (11, 2) if sem in (_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL) else (8, 8)
+    check_pair(orc, sem, q, t, gaps[0], gaps[1], blosum62, directions_only=True)
