@@ -195,7 +195,12 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     if (core && p->heuristics_present) return ALN_ERR_UNNECESSARY_ARGUMENT;
     if (!p->matrix || p->rows == 0 || p->cols == 0) { g_err = "matrix missing"; return ALN_ERR_INVALID_ARGUMENT; }
     if (pwm && p->rows != 4) return ALN_ERR_MATRIX_SHAPE;                      // pwm/mod.rs:40-42
-    if ((uint64_t)p->rows * p->cols > 4096) { g_err = "substitution matrix larger than 4096 entries"; return ALN_ERR_UNSUPPORTED; }
+    // the matrix lives in LDS: 32 KiB next to the query profiles; a position-weight matrix (no profiles in LDS) may be
+    // 4 x 2000 wide (62.5 KiB as f64)
+    if ((uint64_t)p->rows * p->cols > (pwm ? 8000u : 4096u)) {
+        g_err = pwm ? "position-weight matrix larger than 8000 entries (4 x 2000)" : "substitution matrix larger than 4096 entries";
+        return ALN_ERR_UNSUPPORTED;
+    }
     if (n > 0xFFFFFFF0ull) { g_err = "too many pairs"; return ALN_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(ctx->device));
 
