@@ -422,8 +422,9 @@ struct FastStrip {
         const uint32_t kend = uniform32(kb_end * SPB);
         uint32_t qop = (uint32_t)(uintptr_t)qo_lane + 2u * ku;
         const uint32_t prow32 = (uint32_t)(uintptr_t)prow;
-        int kt = (int)uniform32(2047u - (ku & 2047u));
-        int G = 2, X1, O1, np, ta, tb, c0, c1, k0, p0;
+        int kt = (int)uniform32(2032u - (ku & 2047u));       // tracker term of the unit (a step adds 15 - i as an immediate)
+        int G = 2, X1, O1, np, ta, tb, c0, c1, k0, p0, u0, u1;
+        uint64_t um;
         uint32_t P0 = (uint32_t)pw, P1 = (uint32_t)pw1, P2, P3, Q0, Q1, Q2 = qv2, Q3 = qv3, la, w0, w1, w2, w3, st, spin;
         uint32_t vsrc = 4u * (ku + ((16u - (uint32_t)lane) & 15u));
         uint32_t vpub = 4u * (ku + (uint32_t)lane - 111u);          // 4 * column (negative while lanes 48..63 hold nothing)
@@ -466,7 +467,7 @@ struct FastStrip {
           [kt] "+&s"(kt), [ku] "+&s"(ku), [st] "=&s"(st), [spin] "=&s"(spin), [em] "+&s"(em), [et] "=&s"(et), [krem] "+&s"(krem), [w0] "=&v"(w0), [w1] "=&v"(w1), \
           [w2] "=&v"(w2), [w3] "=&v"(w3), [P2] "=&v"(P2), [P3] "=&v"(P3), [Q0] "=&v"(Q0), [Q1] "=&v"(Q1),             \
           [X1] "=&v"(X1), [O1] "=&v"(O1), [np] "=&v"(np), [ta] "=&v"(ta), [tb] "=&v"(tb), [c0] "=&v"(c0),             \
-          [c1] "=&v"(c1), [k0] "=&v"(k0), [p0] "=&v"(p0), [la] "=&v"(la)                                              \
+          [c1] "=&v"(c1), [k0] "=&v"(k0), [p0] "=&v"(p0), [la] "=&v"(la), [u0] "=&v"(u0), [u1] "=&v"(u1), [um] "=&s"(um)                                              \
         : [two] "v"(twov), [prow] "v"(prow32), [ne] "v"(in.ne4), [nd] "v"(in.nd4), [vzero] "v"(vzero),               \
           [kend] "s"(kend), [gin] "s"(sgin), [gout] "s"(sgout), [dbase] "s"(sdbase), [zbase] "s"(szbase),         \
           [abortp] "s"(sabort), [m48] "s"(m48), [zmask] "s"(zmask), [sdirs] "s"(sdirs), [amode] "s"(amode), [n4] "s"(n4), [astep] "s"(astep), [pstep] "s"(pstep), \

@@ -56,6 +56,7 @@ def step(i, R, dw, kind="MID", masked=False):
         L.append("ds_read_b32 %[gL], %[vrin] ;M")
     if masked:
         L.append("s_mov_b64 exec, %[em]")                 # only the lanes whose column exists: 0 <= k - lane < N
+        L.append("s_or_b64 %[um], %[um], %[em]")          # lanes that had a cell in this unit (for the tracker fold)
     if R == 1:
         L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
         L.append("v_cndmask_b32 %[np], %[ne], %[nd], vcc")
@@ -65,9 +66,13 @@ def step(i, R, dw, kind="MID", masked=False):
         L.append("v_and_or_b32 %[TL], %[k0], -4, 2")
         L.append("v_max_u32 %[k0], %[k0], 3")
         L.append("v_mov_b32 %s, %%[TL]" % O_new)
-        L.append("v_lshl_add_u32 %[p0], %[TL], 11, %[kt]")
-        L.append("v_alignbit_b32 %s, %%[k0], %s, 2" % (dw, dw))
-        L.append("v_max_i32 %[r0], %[r0], %[p0]")
+        if i == 0 and not masked:
+            L.append("v_lshl_add_u32 %%[u0], %%[TL], 11, %d" % (15 - i))     # the unit's own tracker starts here
+            L.append("v_alignbit_b32 %s, %%[k0], %s, 2" % (dw, dw))
+        else:
+            L.append("v_lshl_add_u32 %%[p0], %%[TL], 11, %d" % (15 - i))
+            L.append("v_alignbit_b32 %s, %%[k0], %s, 2" % (dw, dw))
+            L.append("v_max_i32 %[u0], %[u0], %[p0]")
     else:
         # row 1's diagonal is row 0's previous cell, its top is row 0's new cell
         L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
@@ -87,15 +92,19 @@ def step(i, R, dw, kind="MID", masked=False):
         L.append("v_and_or_b32 %[TL], %[c1], -4, 2")
         L.append("v_max_u32 %[c1], %[c1], 3")
         L.append("v_mov_b32 %s, %%[TL]" % O_new)
-        L.append("v_lshl_add_u32 %[p0], %[T0], 11, %[kt]")
-        L.append("v_alignbit_b32 %s, %%[c1], %s, 2" % (dw, dw))
-        L.append("v_max_i32 %[r0], %[r0], %[p0]")
-        L.append("v_lshl_add_u32 %[p0], %[TL], 11, %[kt]")
-        L.append("v_max_i32 %[r1], %[r1], %[p0]")
+        if i == 0 and not masked:
+            L.append("v_lshl_add_u32 %%[u0], %%[T0], 11, %d" % (15 - i))
+            L.append("v_alignbit_b32 %s, %%[c1], %s, 2" % (dw, dw))
+            L.append("v_lshl_add_u32 %%[u1], %%[TL], 11, %d" % (15 - i))
+        else:
+            L.append("v_lshl_add_u32 %%[p0], %%[T0], 11, %d" % (15 - i))
+            L.append("v_alignbit_b32 %s, %%[c1], %s, 2" % (dw, dw))
+            L.append("v_max_i32 %[u0], %[u0], %[p0]")
+            L.append("v_lshl_add_u32 %%[p0], %%[TL], 11, %d" % (15 - i))
+            L.append("v_max_i32 %[u1], %[u1], %[p0]")
     if masked:
         # next step's lanes: everything moves up one lane, lane 0 stays in while columns remain (krem = N - 1 - k)
         L.append("s_mov_b64 exec, -1")
-        L.append("s_sub_u32 %[kt], %[kt], 1")
         L.append("s_lshl_b64 %[em], %[em], 1")
         L.append("s_cmp_gt_i32 %[krem], 0")
         L.append("s_cselect_b64 %[et], 1, 0")
@@ -104,7 +113,6 @@ def step(i, R, dw, kind="MID", masked=False):
         L.append("v_mov_b32_dpp %s, %s wave_shl:1 row_mask:0xf bank_mask:0xf" % (O_new, O_old))
         return L
     L.append("v_mov_b32_dpp %s, %s wave_shl:1 row_mask:0xf bank_mask:0xf" % (O_new, O_old))
-    L.append("s_sub_u32 %[kt], %[kt], 1")
     return L
 
 
@@ -237,6 +245,11 @@ def loop(R, kind, masked=False):
             L += acquire(u, uid, masked)
         if kind != "LAST":
             L.append("ds_read_b32 %[chk], %[vrout] ;M")      # LDS publish: are this unit's ring slots free? (looked at below)
+        if masked:
+            L.append("v_mov_b32 %[u0], 0x80000000")          # a lane may join in mid-unit: no cell yet = INT_MIN
+            if R == 2:
+                L.append("v_mov_b32 %[u1], 0x80000000")
+            L.append("s_mov_b64 %[um], 0")
         for i in range(16):
             if R == 1:
                 dw = "%%[w%d]" % u
@@ -244,6 +257,18 @@ def loop(R, kind, masked=False):
                 dw = "%%[w%d]" % (2 * u + (0 if i < 8 else 1))
             L += step(i, R, dw, kind, masked)
         L.append("v_add_u32 %[qop], 32, %[qop]")
+        # end-cell tracker: within the unit the packs carry 15 - i (an inline constant); the unit's term -- 16 * (units
+        # left in the 2048-step chunk), kt = 2047 - (k & 2047) = that + 15 - i -- is added once per unit and row
+        if masked:
+            L.append("s_mov_b64 exec, %[um]")                # lanes that had a cell in this unit
+        L.append("v_add_u32 %[p0], %[u0], %[kt]")
+        L.append("v_max_i32 %[r0], %[r0], %[p0]")
+        if R == 2:
+            L.append("v_add_u32 %[p0], %[u1], %[kt]")
+            L.append("v_max_i32 %[r1], %[r1], %[p0]")
+        if masked:
+            L.append("s_mov_b64 exec, -1")
+        L.append("s_sub_u32 %[kt], %[kt], 16")
         if kind != "LAST":
             L += publish(u, uid, masked)
         else:
