@@ -91,6 +91,8 @@ struct SingleArgs {
     uint32_t R, ns, pass, max_passes;
     uint32_t hazard;
     uint32_t store_dirs;
+    uint32_t test_drop;       // fault injection (env ALN_TEST_DROP_STRIP = s + 1): strip s never runs -- the run must end
+                              // poisoned (ALN_ERR_DEVICE) within the polls' bounds, not hang
 };
 
 // strip 0 of a hazard pair checkpoints its lane state at steps max(16, one quad), then doubling, up to 512

@@ -456,6 +456,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         sa.ns = (d.M + 64 * sa.R - 1) / (64 * sa.R);
         sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
         sa.store_dirs = b->store_dirs ? 1u : 0u;
+        { const char *td = getenv("ALN_TEST_DROP_STRIP"); sa.test_drop = td ? (uint32_t)atoi(td) : 0u; }
         sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
         aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), s);
         // the granule rows must read "not yet produced" before a pass: one memset here, later passes are zeroed by the

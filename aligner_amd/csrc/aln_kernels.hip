@@ -651,6 +651,7 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t strip = blockIdx.x * W + wave;
     if (strip >= a.ns) return;
+    if (a.test_drop != 0 && strip + 1 == a.test_drop) return;       // fault injection, see SingleArgs
     FastIn in;
     in.lane = threadIdx.x & 63;
     in.N = desc.N; in.M = desc.M;

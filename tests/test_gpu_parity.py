@@ -539,3 +539,22 @@ def test_queries_longer_than_one_tracker_chunk(orc, blosum62, sem, shape):
     t = rng.integers(0, 20, M).astype(np.uint8)
     gaps = (11, 2) if sem in (_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL) else (8, 8)
     check_pair(orc, sem, q, t, gaps[0], gaps[1], blosum62, directions_only=True)
+
+
+@pytest.mark.parametrize("drop", ["1", "6", "8"])
+def test_single_pair_lost_producer_poisons_the_run(blosum62, monkeypatch, drop):
+    """Fault injection (ALN_TEST_DROP_STRIP): strip `drop - 1` never runs.  Every strip below it polls a bounded number of
+    times, the run comes back as a device error (never a wrong answer, never a hang), and the next call works."""
+    import time
+    from aligner_amd.errors import DeviceError
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 20, 2000).astype(np.uint8)
+    t = rng.integers(0, 20, 2000).astype(np.uint8)
+    monkeypatch.setenv("ALN_TEST_DROP_STRIP", drop)
+    t0 = time.time()
+    with pytest.raises(DeviceError):
+        runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, blosum62)
+    assert time.time() - t0 < 30
+    monkeypatch.delenv("ALN_TEST_DROP_STRIP")
+    res = runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, blosum62)[0]
+    assert res.status == 0 and res.flags & 2
