@@ -195,7 +195,8 @@ struct FastStrip {
     int qv, top0v;
     uint32_t gpre;             // prefetched granule of the next 16-column group (lanes 0..15)
     // hand-written steady state (single-pair kernel, core local, R <= 2)
-    static constexpr bool ASMPATH = SINGLE && SEM == ALN_CORE_LOCAL && (R == 1 || R == 2) && !(FIRST && LAST);
+    static constexpr bool GLOBAL_ASM = (SEM == ALN_CORE_GLOBAL);   // six-instruction cells, border group instead of the constant 2
+    static constexpr bool ASMPATH = SINGLE && (SEM == ALN_CORE_LOCAL || SEM == ALN_CORE_GLOBAL) && (R == 1 || R == 2) && !(FIRST && LAST);
     int twov;                  // 2; lane 0 of strip 0: a value no cell takes (row 1's penalty never follows the border)
     PW pw1;                    // steady format (see steady_enter)
     uint32_t qv2, qv3, gA, gB;
@@ -422,8 +423,12 @@ struct FastStrip {
         const uint32_t kend = uniform32(kb_end * SPB);
         uint32_t qop = (uint32_t)(uintptr_t)qo_lane + 2u * ku;
         const uint32_t prow32 = (uint32_t)(uintptr_t)prow;
-        int kt = (int)uniform32(2032u - (ku & 2047u));       // tracker term of the unit (a step adds 15 - i as an immediate)
-        int G = 2, X1, O1, np, ta, tb, c0, c1, k0, p0, u0, u1;
+        // core local: tracker term of the unit (a step adds 15 - i as an immediate).  Core global, strip 0: what the border
+        // H[0][x] = -x del moves by per unit of 16 columns, and G = the border above the unit's columns (lane i: column
+        // ku + (16 - i) % 16, i.e. x = that + 1); the corner column N never falls into this loop (see run()).
+        int kt = (int)uniform32(GLOBAL_ASM ? (uint32_t)(16 * in.nd4) : 2032u - (ku & 2047u));
+        int G = (GLOBAL_ASM && FIRST) ? 2 + (int)(ku + ((16u - (uint32_t)lane) & 15u) + 1u) * in.nd4 : 2;
+        int X1, O1, np, ta, tb, c0, c1, k0, p0, u0, u1;
         uint64_t um;
         uint32_t P0 = (uint32_t)pw, P1 = (uint32_t)pw1, P2, P3, Q0, Q1, Q2 = qv2, Q3 = qv3, la, w0, w1, w2, w3, st, spin;
         uint32_t vsrc = 4u * (ku + ((16u - (uint32_t)lane) & 15u));
@@ -473,24 +478,27 @@ struct FastStrip {
           [abortp] "s"(sabort), [m48] "s"(m48), [zmask] "s"(zmask), [sdirs] "s"(sdirs), [amode] "s"(amode), [n4] "s"(n4), [astep] "s"(astep), [pstep] "s"(pstep), \
           [pmode] "s"(pmode), [vrmask] "v"(vrmask), [vrbin] "v"(vrbin), [vrbout] "v"(vrbout)                          \
         : "vcc", "scc", "memory"
+#define ALN_PICK(L1F, L1M, L1L, L2F, L2M, L2L)                                                                  \
+        if constexpr (R == 1) {                                                                                \
+            if constexpr (FIRST) asm volatile(L1F ALN_STEADY_OPERANDS);                                        \
+            else if constexpr (LAST) asm volatile(L1L ALN_STEADY_OPERANDS);                                    \
+            else asm volatile(L1M ALN_STEADY_OPERANDS);                                                        \
+        } else {                                                                                               \
+            if constexpr (FIRST) asm volatile(L2F ALN_STEADY_OPERANDS);                                        \
+            else if constexpr (LAST) asm volatile(L2L ALN_STEADY_OPERANDS);                                    \
+            else asm volatile(L2M ALN_STEADY_OPERANDS);                                                        \
+        }
         if constexpr (MASKED) {
             static_assert(!FIRST, "strip 0 runs its ends in C++ (its first column takes del, and nothing waits on its start)");
-            if constexpr (R == 1) {
-                if constexpr (LAST) asm volatile(ALN_MASKED_ASM_R1_LAST ALN_STEADY_OPERANDS);
-                else asm volatile(ALN_MASKED_ASM_R1_MID ALN_STEADY_OPERANDS);
-            } else {
-                if constexpr (LAST) asm volatile(ALN_MASKED_ASM_R2_LAST ALN_STEADY_OPERANDS);
-                else asm volatile(ALN_MASKED_ASM_R2_MID ALN_STEADY_OPERANDS);
-            }
-        } else if constexpr (R == 1) {
-            if constexpr (FIRST) asm volatile(ALN_STEADY_ASM_R1_FIRST ALN_STEADY_OPERANDS);
-            else if constexpr (LAST) asm volatile(ALN_STEADY_ASM_R1_LAST ALN_STEADY_OPERANDS);
-            else asm volatile(ALN_STEADY_ASM_R1_MID ALN_STEADY_OPERANDS);
+            // (the FIRST slots of the masked picks are never instantiated)
+            if constexpr (GLOBAL_ASM) { ALN_PICK(ALN_GMASKED_ASM_R1_MID, ALN_GMASKED_ASM_R1_MID, ALN_GMASKED_ASM_R1_LAST, ALN_GMASKED_ASM_R2_MID, ALN_GMASKED_ASM_R2_MID, ALN_GMASKED_ASM_R2_LAST) }
+            else { ALN_PICK(ALN_MASKED_ASM_R1_MID, ALN_MASKED_ASM_R1_MID, ALN_MASKED_ASM_R1_LAST, ALN_MASKED_ASM_R2_MID, ALN_MASKED_ASM_R2_MID, ALN_MASKED_ASM_R2_LAST) }
+        } else if constexpr (GLOBAL_ASM) {
+            ALN_PICK(ALN_GSTEADY_ASM_R1_FIRST, ALN_GSTEADY_ASM_R1_MID, ALN_GSTEADY_ASM_R1_LAST, ALN_GSTEADY_ASM_R2_FIRST, ALN_GSTEADY_ASM_R2_MID, ALN_GSTEADY_ASM_R2_LAST)
         } else {
-            if constexpr (FIRST) asm volatile(ALN_STEADY_ASM_R2_FIRST ALN_STEADY_OPERANDS);
-            else if constexpr (LAST) asm volatile(ALN_STEADY_ASM_R2_LAST ALN_STEADY_OPERANDS);
-            else asm volatile(ALN_STEADY_ASM_R2_MID ALN_STEADY_OPERANDS);
+            ALN_PICK(ALN_STEADY_ASM_R1_FIRST, ALN_STEADY_ASM_R1_MID, ALN_STEADY_ASM_R1_LAST, ALN_STEADY_ASM_R2_FIRST, ALN_STEADY_ASM_R2_MID, ALN_STEADY_ASM_R2_LAST)
         }
+#undef ALN_PICK
 #undef ALN_STEADY_OPERANDS
         pw = (PW)P0; pw1 = (PW)P1; qv2 = Q2; qv3 = Q3;
         bottom = Tl[R - 1];
@@ -640,7 +648,10 @@ struct FastStrip {
         const uint32_t nkb = aln_strip_blocks(nsteps, SPB);
         // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
         const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
-        const uint32_t kb_steady1 = max(kb_steady0, min(nkb, (N / (4 * SPB)) * 4u));
+        uint32_t kb_steady1 = max(kb_steady0, min(nkb, (N / (4 * SPB)) * 4u));
+        // core global, strip 0: step N - 1 reads the overwritten corner H[0][N] = -(N + 1) del (simple/mod.rs:62), which the
+        // border group of the asm loop does not know: that quad stays with the C++ step
+        if (ASMPATH && GLOBAL_ASM && FIRST && kb_steady1 * SPB >= N && kb_steady1 >= kb_steady0 + 4u) kb_steady1 -= 4u;
         // Segment ends: the 2048-step chunks of the end-cell tracker and, for strip 0 of a hazard pair, the
         // checkpoint steps 64, 128, 256, 512.
         const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0;

@@ -1241,7 +1241,7 @@ extern "C" uint32_t aln_single_lds_bytes(uint32_t rows, uint32_t cols, uint32_t 
 extern "C" uint32_t aln_single_waves(int semantics, uint32_t R, uint32_t rows, uint32_t cols, uint32_t N, uint32_t ns)
 {
     if (getenv("ALN_SINGLE_W1")) return 1;
-    if (semantics != ALN_CORE_LOCAL || R > 2 || ns < 2) return 1;
+    if ((semantics != ALN_CORE_LOCAL && semantics != ALN_CORE_GLOBAL) || R > 2 || ns < 2) return 1;
     return aln_single_lds_bytes(rows, cols, R, N, 4) <= 150u * 1024u ? 4u : 1u;
 }
 extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_serial, hipStream_t s)
@@ -1266,19 +1266,24 @@ extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_seri
         hipLaunchKernelGGL((aln_single_finalize_kernel<SEM>), dim3(1), dim3(1024), 0, s, *a);                    \
         if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<SEM>), dim3(1), dim3(64), serial_lds, s, *a); \
     } while (0)
+#define ALN_SINGLE4(SEM)                                                                                       \
+    do {                                                                                                       \
+        if (a->R == 1) ALN_SINGLE_LAUNCH(SEM, 1, 4);                                                           \
+        else ALN_SINGLE_LAUNCH(SEM, 2, 4);                                                                     \
+        hipLaunchKernelGGL((aln_single_finalize_kernel<SEM>), dim3(1), dim3(1024), 0, s, *a);                  \
+        if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<SEM>), dim3(1), dim3(64), serial_lds, s, *a); \
+    } while (0)
     switch (a->semantics) {
-    case ALN_CORE_GLOBAL: ALN_SINGLE(ALN_CORE_GLOBAL); break;
+    case ALN_CORE_GLOBAL:
+        if (W == 4) ALN_SINGLE4(ALN_CORE_GLOBAL); else ALN_SINGLE(ALN_CORE_GLOBAL);
+        break;
     case ALN_CORE_LOCAL:
-        if (W == 4) {
-            if (a->R == 1) ALN_SINGLE_LAUNCH(ALN_CORE_LOCAL, 1, 4);
-            else ALN_SINGLE_LAUNCH(ALN_CORE_LOCAL, 2, 4);
-            hipLaunchKernelGGL((aln_single_finalize_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(1024), 0, s, *a);
-            if (with_serial) hipLaunchKernelGGL((aln_single_serial_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(64), serial_lds, s, *a);
-        } else ALN_SINGLE(ALN_CORE_LOCAL);
+        if (W == 4) ALN_SINGLE4(ALN_CORE_LOCAL); else ALN_SINGLE(ALN_CORE_LOCAL);
         break;
     case ALN_LEGACY_GLOBAL: ALN_SINGLE(ALN_LEGACY_GLOBAL); break;
     default: ALN_SINGLE(ALN_LEGACY_LOCAL); break;
     }
+#undef ALN_SINGLE4
 #undef ALN_SINGLE
 #undef ALN_SINGLE_LAUNCH
 }

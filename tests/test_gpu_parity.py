@@ -558,3 +558,20 @@ def test_single_pair_lost_producer_poisons_the_run(blosum62, monkeypatch, drop):
     monkeypatch.delenv("ALN_TEST_DROP_STRIP")
     res = runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, blosum62)[0]
     assert res.status == 0 and res.flags & 2
+
+
+@pytest.mark.parametrize("r", ["1", "2"])
+@pytest.mark.parametrize("shape", [(992, 300), (1024, 700), (2498, 938), (777, 1031)])
+def test_single_pair_kernel_core_global(orc, blosum62, monkeypatch, r, shape):
+    """The single-pair route's asm loop for the core-global semantics (six-instruction cells; strip 0 feeds the border
+    H[0][x] = -x del through the group register).  N a multiple of the quad keeps the overwritten corner H[0][N] out of
+    that loop (simple/mod.rs:62); every direction, the corner score and both strings."""
+    monkeypatch.setenv("ALN_SINGLE_R", r)
+    N, M = shape
+    rng = np.random.default_rng(N * 7 + M)
+    q = rng.integers(0, 20, N).astype(np.uint8)
+    t = rng.integers(0, 20, M).astype(np.uint8)
+    t[M // 4:M // 4 + min(N, M) // 2] = q[N // 4:N // 4 + min(N, M) // 2][:len(t[M // 4:M // 4 + min(N, M) // 2])]
+    for gaps in ((11, 2), (3, 3)):
+        res = check_pair(orc, _ffi.CORE_GLOBAL, q, t, gaps[0], gaps[1], blosum62, directions_only=True)
+        assert res.flags & 2

@@ -164,15 +164,16 @@ def test_generated_asm_is_in_sync_with_its_generator(tmp_path):
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     committed = open(os.path.join(ROOT, "aligner_amd", "csrc", "aln_single_unit.inc")).read()
-    for R in (1, 2):
+    for sem, prefix in (("LOCAL", ""), ("GLOBAL", "G")):
+      for R in (1, 2):
         for kind in ("FIRST", "MID", "LAST"):
             for masked in ((False,) if kind == "FIRST" else (False, True)):
-                lines = gen.loop(R, kind, masked)
+                lines = gen.loop(R, kind, masked, sem)
                 assert "WAIT" not in lines and not any(";M" in ln for ln in lines)
                 assert lines[-1] == "s_waitcnt vmcnt(0) lgkmcnt(0)"
                 labels = [ln for ln in lines if ln.endswith(":")]
                 assert len(labels) == len(set(labels))
-                name = "ALN_%s_ASM_R%d_%s" % ("MASKED" if masked else "STEADY", R, kind)
+                name = "ALN_%s%s_ASM_R%d_%s" % (prefix, "MASKED" if masked else "STEADY", R, kind)
                 body = committed[committed.index("#define " + name):]
                 body = body[:body.index("\n\n")]
                 got = [ln.strip().rstrip("\\").strip().strip('"').replace("\\n\\t", "") for ln in body.splitlines()[1:]]

@@ -35,7 +35,7 @@ import os
 SDWA = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_%d"
 
 
-def step(i, R, dw, kind="MID", masked=False):
+def step(i, R, dw, kind="MID", masked=False, sem="LOCAL"):
     X_old, X_new = "%%[X%d]" % (i % 2), "%%[X%d]" % ((i + 1) % 2)
     O_old, O_new = "%%[O%d]" % (i % 2), "%%[O%d]" % ((i + 1) % 2)
     P_cur, P_nxt = "%%[P%d]" % (i % 4), "%%[P%d]" % ((i + 2) % 4)
@@ -45,7 +45,8 @@ def step(i, R, dw, kind="MID", masked=False):
     L = []
     L.append("v_mov_b32_dpp %s, %%[G] %s row_mask:0x1 bank_mask:0x1" % (X_new, ror))
     L.append("v_mov_b32_dpp %s, %%[TL] wave_shr:1 row_mask:0xf bank_mask:0xf" % X_new)
-    L.append("v_cmp_eq_u32 vcc, %%[two], %s" % X_new)
+    if sem == "LOCAL":
+        L.append("v_cmp_eq_u32 vcc, %%[two], %s" % X_new)
     L.append("WAIT")                                      # for the two reads issued two steps ago (count filled in later)
     L.append("v_add_u32 %%[la], %%[prow], %s" % Q_adr)
     L.append("%s %s, %%[la] ;M" % (pwread, P_nxt))
@@ -57,7 +58,32 @@ def step(i, R, dw, kind="MID", masked=False):
     if masked:
         L.append("s_mov_b64 exec, %[em]")                 # only the lanes whose column exists: 0 <= k - lane < N
         L.append("s_or_b64 %[um], %[um], %[em]")          # lanes that had a cell in this unit (for the tracker fold)
-    if R == 1:
+    if sem == "GLOBAL":
+        # core global (simple/mod.rs:72-98): the carried penalty is ext everywhere past cell (1,1); no Beginning inside the
+        # matrix, no end-cell tracker: six instructions per cell
+        if R == 1:
+            L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
+            L.append("v_add_u32 %%[ta], %s, %%[ne]" % X_new)
+            L.append("v_add3_u32 %[tb], %[TL], %[ne], -1")
+            L.append("v_max3_i32 %[k0], %[ta], %[tb], %[c0]")
+            L.append("v_and_or_b32 %[TL], %[k0], -4, 2")
+            L.append("v_alignbit_b32 %s, %%[k0], %s, 2" % (dw, dw))
+            L.append("v_mov_b32 %s, %%[TL]" % O_new)
+        else:
+            L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
+            L.append("v_add_u32_sdwa %%[c1], %%[T0], sext(%s) %s" % (P_cur, SDWA % 1))
+            L.append("v_add_u32 %%[ta], %s, %%[ne]" % X_new)
+            L.append("v_add3_u32 %[tb], %[T0], %[ne], -1")
+            L.append("v_max3_i32 %[k0], %[ta], %[tb], %[c0]")
+            L.append("v_and_or_b32 %[T0], %[k0], -4, 2")
+            L.append("v_alignbit_b32 %s, %%[k0], %s, 2" % (dw, dw))
+            L.append("v_add_u32 %[ta], %[T0], %[ne]")
+            L.append("v_add3_u32 %[tb], %[TL], %[ne], -1")
+            L.append("v_max3_i32 %[c1], %[ta], %[tb], %[c1]")
+            L.append("v_and_or_b32 %[TL], %[c1], -4, 2")
+            L.append("v_alignbit_b32 %s, %%[c1], %s, 2" % (dw, dw))
+            L.append("v_mov_b32 %s, %%[TL]" % O_new)
+    elif R == 1:
         L.append("v_add_u32_sdwa %%[c0], %s, sext(%s) %s" % (X_old, P_cur, SDWA % 0))
         L.append("v_cndmask_b32 %[np], %[ne], %[nd], vcc")
         L.append("v_add_u32 %%[ta], %s, %%[np]" % X_new)
@@ -235,7 +261,7 @@ def publish(u, uid, masked=False):
     return L
 
 
-def loop(R, kind, masked=False):
+def loop(R, kind, masked=False, sem="LOCAL"):
     U = 4 // R                      # units per quad
     uid = "%="
     L = []
@@ -245,30 +271,36 @@ def loop(R, kind, masked=False):
             L += acquire(u, uid, masked)
         if kind != "LAST":
             L.append("ds_read_b32 %[chk], %[vrout] ;M")      # LDS publish: are this unit's ring slots free? (looked at below)
-        if masked:
+        if masked and sem == "LOCAL":
             L.append("v_mov_b32 %[u0], 0x80000000")          # a lane may join in mid-unit: no cell yet = INT_MIN
             if R == 2:
                 L.append("v_mov_b32 %[u1], 0x80000000")
+        if masked:
             L.append("s_mov_b64 %[um], 0")
         for i in range(16):
             if R == 1:
                 dw = "%%[w%d]" % u
             else:
                 dw = "%%[w%d]" % (2 * u + (0 if i < 8 else 1))
-            L += step(i, R, dw, kind, masked)
+            L += step(i, R, dw, kind, masked, sem)
         L.append("v_add_u32 %[qop], 32, %[qop]")
         # end-cell tracker: within the unit the packs carry 15 - i (an inline constant); the unit's term -- 16 * (units
         # left in the 2048-step chunk), kt = 2047 - (k & 2047) = that + 15 - i -- is added once per unit and row
-        if masked:
-            L.append("s_mov_b64 exec, %[um]")                # lanes that had a cell in this unit
-        L.append("v_add_u32 %[p0], %[u0], %[kt]")
-        L.append("v_max_i32 %[r0], %[r0], %[p0]")
-        if R == 2:
-            L.append("v_add_u32 %[p0], %[u1], %[kt]")
-            L.append("v_max_i32 %[r1], %[r1], %[p0]")
-        if masked:
-            L.append("s_mov_b64 exec, -1")
-        L.append("s_sub_u32 %[kt], %[kt], 16")
+        if sem == "LOCAL":
+            if masked:
+                L.append("s_mov_b64 exec, %[um]")            # lanes that had a cell in this unit
+            L.append("v_add_u32 %[p0], %[u0], %[kt]")
+            L.append("v_max_i32 %[r0], %[r0], %[p0]")
+            if R == 2:
+                L.append("v_add_u32 %[p0], %[u1], %[kt]")
+                L.append("v_max_i32 %[r1], %[r1], %[p0]")
+            if masked:
+                L.append("s_mov_b64 exec, -1")
+            L.append("s_sub_u32 %[kt], %[kt], 16")
+        elif kind == "FIRST":
+            # core global, strip 0: the row above is the border H[0][x] = -x del (simple/mod.rs:59-62); G holds it for the
+            # unit's 16 columns and moves on by 16 columns' worth (kt = -64 del in T units)
+            L.append("v_add_u32 %[G], %[kt], %[G]")
         if kind != "LAST":
             L += publish(u, uid, masked)
         else:
@@ -348,6 +380,18 @@ def main():
                     lines = loop(R, kind, masked=True)
                     f.write("// R = %d, %s strip: masked quads (ramp-up / tail)\n" % (R, kind))
                     f.write("#define ALN_MASKED_ASM_R%d_%s \\\n" % (R, kind))
+                    for j, ln in enumerate(lines):
+                        last = j + 1 == len(lines)
+                        f.write('    "%s%s"%s\n' % (ln, "" if last else "\\n\\t", "" if last else " \\"))
+                    f.write("\n")
+        # core global: same loops, six-instruction cells
+        for R in (1, 2):
+            for kind in ("FIRST", "MID", "LAST"):
+                for masked in ((False,) if kind == "FIRST" else (False, True)):
+                    lines = loop(R, kind, masked, sem="GLOBAL")
+                    name = "ALN_G%s_ASM_R%d_%s" % ("MASKED" if masked else "STEADY", R, kind)
+                    f.write("// core global, R = %d, %s strip%s\n" % (R, kind, ", masked quads" if masked else ""))
+                    f.write("#define %s \\\n" % name)
                     for j, ln in enumerate(lines):
                         last = j + 1 == len(lines)
                         f.write('    "%s%s"%s\n' % (ln, "" if last else "\\n\\t", "" if last else " \\"))
