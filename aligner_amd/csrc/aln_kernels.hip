@@ -988,22 +988,42 @@ __device__ __forceinline__ bool walk_in_strip(Fetch fetch, uint32_t y0, uint32_t
 // LDS quads of the traceback kernels' window: 768 wave steps (48 KiB at most)
 __host__ __device__ inline uint32_t tb_window_quads(uint32_t R) { const uint32_t q = 12u * R; return q > 48u ? 48u : q; }
 
+// Exit maps are computed only where the path can plausibly enter a strip: a band of TB_BAND columns around the line of
+// slope 1 through the traceback's start cell (insertions push the path left of it, deletions right).  The chain kernel
+// uses a map entry when the real entry column falls into the band and walks the strip itself when it does not, so the
+// band is a speed choice, never a correctness one.  Strips below the start cell need no map at all.
+#define TB_BAND 1024u
+__device__ __forceinline__ bool tb_band(uint32_t ey, uint32_t ex, uint32_t yb, uint32_t N, uint32_t &c_lo, uint32_t &c_hi)
+{
+    if (yb > ey) return false;                                   // the path never enters this strip from below
+    const uint32_t dy = ey - yb;
+    const uint32_t c = ex > dy ? ex - dy : 0u;                   // column of the slope-1 line on the strip's bottom row
+    c_lo = c > TB_BAND / 2u ? c - TB_BAND / 2u : 0u;
+    c_hi = min(N, c_lo + TB_BAND - 1u);
+    return true;
+}
+
 // exit map: thread (x, s) enters strip s on its bottom row at column x; the block's 256 walks share one staged window
 extern "C" __global__ __launch_bounds__(256) void aln_tb_single_maps_kernel(TraceSingleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_words[];
     const PairDesc &d = a.descs[a.pair];
     if (a.results[a.pair].status != ALN_OK || (d.layout & 0xffu) != ALN_LAYOUT_UNIFORM) return;   // serial fallback: aln_traceback_kernel
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    const uint32_t s = blockIdx.y;
     const uint32_t lgR = 31u - (uint32_t)__builtin_clz(a.R), rows = 64u << lgR;
     const uint32_t y0 = s * rows;
     const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
+    const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
     const uint32_t cy0 = min(d.M, y0 + rows);
-    const uint32_t x_hi = min(d.N, blockIdx.x * blockDim.x + blockDim.x - 1u);
+    uint32_t c_lo, c_hi;
+    if (!tb_band(a.results[a.pair].end_y - (legacy ? 1u : 0u), a.results[a.pair].end_x - (legacy ? 1u : 0u), cy0, d.N, c_lo, c_hi)) return;
+    if (c_lo + blockIdx.x * blockDim.x > c_hi) return;           // (uniform over the block)
+    const uint32_t x = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t x_hi = min(c_hi, c_lo + blockIdx.x * blockDim.x + blockDim.x - 1u);
     const uint32_t k_hi = (x_hi ? x_hi - 1u : 0u) + ((cy0 - 1u - y0) >> lgR);
     const StripWindow w = stage_window(wbase, smem_words, tb_window_quads(a.R), k_hi, lgR);
-    if (x > d.N) return;
+    if (x > c_hi) return;
     uint32_t cy = cy0, cx = x, steps = 0;
     const uint32_t q_lo = w.q_lo, q_n = w.q_n;
     // LDS through an address-space-3 pointer: a generic pointer would turn the two loads into one flat_load with a select
@@ -1031,6 +1051,7 @@ extern "C" __global__ void aln_tb_single_chain_kernel(TraceSingleArgs a)
     const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
     uint32_t cy = res.end_y, cx = res.end_x;
     if (legacy) { cy -= 1; cx -= 1; }
+    const uint32_t cy_start = cy, cx_start = cx;             // the cell the band of the exit maps is centred on
     uint32_t off = 0;
     bool stopped = (cy == 0 || cx == 0) && (!global || (cy == 0 && cx == 0));
     if (!stopped && cy == 0) {                       // only the top border is left (global)
@@ -1046,11 +1067,21 @@ extern "C" __global__ void aln_tb_single_chain_kernel(TraceSingleArgs a)
         uint32_t steps = 0;
         stopped = walk_in_strip(fetch, s * rows, lgR, d.N, global, cy, cx, steps, nullptr);
         off = steps;
+        const uint32_t ey = cy_start, ex = cx_start;
         while (!stopped && s > 0) {
             --s;
             a.seg[s] = make_uint4(cy, cx, off, 1);
-            const uint4 m = a.map[(size_t)s * (d.N + 1) + cx];
-            cx = m.x; cy = m.y; off += m.z; stopped = m.w != 0;
+            uint32_t c_lo, c_hi;
+            if (tb_band(ey, ex, cy, d.N, c_lo, c_hi) && cx >= c_lo && cx <= c_hi) {
+                const uint4 m = a.map[(size_t)s * (d.N + 1) + cx];
+                cx = m.x; cy = m.y; off += m.z; stopped = m.w != 0;
+            } else {                                             // outside the band: walk this strip here
+                const uint32_t *wb = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
+                auto fetch2 = [&](uint32_t kb, uint32_t lane) -> uint32_t { return wb[(((uint64_t)(kb >> 2) * 64u + lane) << 2) + (kb & 3u)]; };
+                uint32_t st = 0;
+                stopped = walk_in_strip(fetch2, s * rows, lgR, d.N, global, cy, cx, st, nullptr);
+                off += st;
+            }
         }
         if (!stopped && global && cy == 0 && cx != 0) {      // left strip 0 through the top border: D[0][x] = Left
             // (walk_in_strip handles the borders inside strip 0, so this cannot happen; kept as a guard)
@@ -1303,7 +1334,8 @@ extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s)
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s)
 {
     const uint32_t lds = tb_window_quads(a->R) * 1024u;
-    hipLaunchKernelGGL(aln_tb_single_maps_kernel, dim3((N + 1 + 255) / 256, a->ns), dim3(256), lds, s, *a);
+    (void)N;
+    hipLaunchKernelGGL(aln_tb_single_maps_kernel, dim3(TB_BAND / 256u, a->ns), dim3(256), lds, s, *a);
     hipLaunchKernelGGL(aln_tb_single_chain_kernel, dim3(1), dim3(64), 0, s, *a);
     hipLaunchKernelGGL(aln_tb_single_segments_kernel, dim3(a->ns), dim3(256), lds, s, *a);
 }

@@ -575,3 +575,16 @@ def test_single_pair_kernel_core_global(orc, blosum62, monkeypatch, r, shape):
     for gaps in ((11, 2), (3, 3)):
         res = check_pair(orc, _ffi.CORE_GLOBAL, q, t, gaps[0], gaps[1], blosum62, directions_only=True)
         assert res.flags & 2
+
+
+@pytest.mark.parametrize("sem", [_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL])
+def test_single_pair_traceback_outside_the_exit_map_band(orc, blosum62, sem):
+    """The exit maps of the single-pair traceback cover a band of 1024 columns around the slope-1 line through the start
+    cell; a path with a 1000-column gap leaves it, and the chain kernel then walks those strips itself."""
+    rng = np.random.default_rng(404)
+    a = rng.integers(0, 20, 1000).astype(np.uint8)
+    b = rng.integers(0, 20, 1000).astype(np.uint8)
+    x = rng.integers(0, 20, 1000).astype(np.uint8)
+    for q, t in ((np.concatenate([a, x, b]), np.concatenate([a, b])), (np.concatenate([a, b]), np.concatenate([a, x, b]))):
+        res = check_pair(orc, sem, q, t, 11, 2, blosum62, full=False)
+        assert res.flags & 2 and res.aln_len > 2900
