@@ -55,6 +55,7 @@ struct FillArgs {
     uint8_t *scratch;         // per-wave scratch base
     uint64_t scratch_stride;  // bytes per wave
     uint32_t max_len;         // max over pairs of max(N, M): sizes the scratch arrays
+    uint64_t max_cells;       // max over the queue's pairs of N * M (the first pair of the LPT order): scales the wave priorities
     const void *matrix;       // device copy, contiguous rows x cols, int32 or double
     uint32_t prof_stride;     // fast kernels: bytes of one wave's LDS query profile (cols * 512)
     uint32_t rows, cols;

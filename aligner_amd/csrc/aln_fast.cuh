@@ -707,6 +707,13 @@ struct FastStrip {
                 }
                 ++slot;
                 next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
+                // a repair that has run out of checkpoints, or has moved the strip's bottom row, cannot succeed any more:
+                // stop here (in this mode every step of lane 63 waits for a load of the old bottom row -- run to its end,
+                // a failed repair cost as much as a full pass)
+                if (in.ck_mode == 2 && (next_ck == 0xffffffffu || __any(brow_bad))) {
+                    o.brow_bad = o.brow_bad || brow_bad;
+                    return o;
+                }
             }
             if (kb * SPB == chunk_base + 2048u) {         // every semantics advances the chunk; only the local ones track an end cell
                 if (LOCAL) fold(o, chunk_base);

@@ -85,6 +85,7 @@ struct aln_batch {
     std::vector<uint32_t> single_pairs;
     std::vector<uint32_t> single_r;
     size_t n_small = 0;
+    uint64_t max_cells = 0;
     uint32_t *d_granules = nullptr;
     uint64_t granule_bytes = 0;
     uint8_t *d_advice1 = nullptr;
@@ -323,6 +324,8 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
         return (uint64_t)b->descs[a].N * b->descs[a].M > (uint64_t)b->descs[c].N * b->descs[c].M;
     });
 
+    b->max_cells = order.empty() ? 0 : (uint64_t)b->descs[order[0]].N * b->descs[order[0]].M;
+
     // ---- grid: persistent waves, 4 per workgroup
     const uint32_t wg_needed = (uint32_t)((b->n_small + 3) / 4);
     b->grid = std::max(1u, std::min(wg_needed, (uint32_t)ctx->cus * 4u));
@@ -431,6 +434,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
     fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
     fa.no_repair = getenv("ALN_NO_REPAIR") ? 1u : 0u;
+    fa.max_cells = b->max_cells;
     fa.store_dirs = b->store_dirs ? 1u : 0u;
     fa.pwm = b->pwm ? 1u : 0u;
     fa.pwm_words = b->d_pwm_words;

@@ -501,12 +501,16 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
                 ro.repaired = false; ro.brow_bad = false;
                 ro = fast_strip<SEM, PWM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : ALN_FULL_R);
                 __threadfence_block();
-                if (!__any(ro.repaired) || __any(ro.brow_bad)) break;     // escalate to a full pass
+                if (!__any(ro.repaired) || __any(ro.brow_bad)) {          // escalate to a full pass
+                    passes |= __any(ro.brow_bad) ? 0x200000u : 0x300000u;   // diagnostics (bits 20..23): why
+                    break;
+                }
                 passes = (passes & ~0xf0000u) | ((ro.ck_slot + 1u) << 16);  // diagnostics: where the repair re-converged
                 if (ns > 1) { converged = true; break; }                  // the bottom strip, hence z, is untouched
                 converged = adopt_advice_zdw(in.advice, reinterpret_cast<const uint32_t *>(in.zrow), N, M, lane, last_flip);   // single strip: z may have moved
             }
             if (converged) break;
+            if (!(passes & 0xf00000u)) passes |= last_flip > 512 ? 0x100000u : 0x400000u;
         }
         if ((passes & 0xffu) >= max_passes) break;
     }
@@ -548,6 +552,20 @@ __device__ __forceinline__ void skip_invalid(aln_pair_result &res, int status, i
         res.f = 0.0; res.score = 0.0; res.end_y = res.end_x = res.start_y = res.start_x = 0;
         res.aln_len = 0; res.status = status; res.passes = 0; res.flags = 0;
     }
+}
+
+// The SIMD's instruction arbiter is not fair: among waves of equal priority the oldest wave issues first, and with three
+// VALU-bound waves per SIMD the youngest gets ~13 % of the issue slots (measured: 1.5 / 0.9 / 0.35 GCUPS for the three).
+// Throughput does not care, the tail of a small batch does: a large pair taken at t = 0 by a youngest wave was still in its
+// first pass when everything else had finished.  So the wave's priority follows the size of its pair (quartiles of the
+// queue's largest pair): in the LPT order this is "oldest pair first" -- a large pair is never starved by the smaller pairs
+// the older waves of its SIMD move on to.
+__device__ __forceinline__ void set_wave_priority(uint64_t cells, uint64_t max_cells)
+{
+    if (4 * cells > 3 * max_cells) __builtin_amdgcn_s_setprio(3);
+    else if (2 * cells > max_cells) __builtin_amdgcn_s_setprio(2);
+    else if (4 * cells > max_cells) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
 }
 
 template <typename SC, int SEM>
@@ -613,6 +631,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
         PairDesc &desc = a.descs[pair];
         aln_pair_result &res = a.results[pair];
         if (desc.status != ALN_OK) { skip_invalid(res, desc.status, in.lane); continue; }
+        set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
         do_pair_fast<SEM, PWM>(in, a, desc, res, (int)a.del, (int)a.ext);
     }
 }

@@ -85,7 +85,9 @@ typedef struct aln_pair_result {
     uint32_t aln_len;           /* length of both aligned strings (includes the reference's duplicated seed pair) */
     int32_t status;             /* enum aln_status for this pair */
     uint32_t passes;            /* bits 0-6: full fill passes (1 unless CORE_LOCAL with del != ext); bit 7: strict-order fallback;
-                                   bits 8-15: localized repairs of strip 0; bits 16-19: 1 + checkpoint at which the last one re-converged */
+                                   bits 8-15: localized repairs of strip 0; bits 16-19: 1 + checkpoint at which the last one re-converged;
+                                   bits 20-23: why a repair escalated to a full pass (1 hazard beyond the last checkpoint, 2 strip 0's
+                                   bottom row moved, 3 no re-convergence, 4 repair limit); diagnostics only */
     uint32_t flags;             /* bit0: integer kernels were used; bit1: the strip-pipelined single-pair route */
 } aln_pair_result;
 
