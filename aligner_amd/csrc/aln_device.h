@@ -55,6 +55,8 @@ struct FillArgs {
     uint8_t *scratch;         // per-wave scratch base
     uint64_t scratch_stride;  // bytes per wave
     uint32_t max_len;         // max over pairs of max(N, M): sizes the scratch arrays
+    uint32_t *doneq;          // optional (overlapped traceback): completion queue, pair + 1 per entry in the order the pairs finish;
+                              // zeroed with the counter; its tail is counter[1]
     uint64_t max_cells;       // max over the queue's pairs of N * M (the first pair of the LPT order): scales the wave priorities
     const void *matrix;       // device copy, contiguous rows x cols, int32 or double
     uint32_t prof_stride;     // fast kernels: bytes of one wave's LDS query profile (cols * 512)
@@ -110,6 +112,13 @@ struct TraceArgs {
     int32_t semantics;
     uint8_t blank;
     uint8_t pwm;
+    // overlapped traceback (aln_traceback_overlap_kernel runs beside the fill kernel; aln_traceback_kernel then sweeps up)
+    uint32_t *walked;         // per pair: the epoch of the run in which the overlap kernel walked it (null: no overlap)
+    uint32_t epoch;
+    const uint32_t *doneq;    // the fill kernel's completion queue (pair + 1, zero = not yet)
+    uint32_t *head;           // next entry of the completion queue to hand to a walk wave
+    uint32_t n_order;         // entries the queue will hold (the fill queue's pairs)
+    uint64_t wait_ticks;      // give up on a chunk after this many 100 MHz ticks (the sweep walks what is left)
 };
 
 // Parallel traceback of one large pair (uniform-R layout): per strip and entry column an "exit map", then a short

@@ -126,6 +126,7 @@ struct FastIn {
     bool hazard;
     bool adv_any;             // single-pair kernel: the advice may hold non-zero bytes (second and later passes)
     bool store_dirs;          // false: score-only (the packed directions are not written)
+    bool wt_dirs;             // batch kernels: direction quads are stored write-through (a walk kernel on another XCD reads them while this kernel runs)
     bool pwm;                 // position-weight-matrix scoring (batch kernels only)
     const uint32_t *pwm_words;// per column: int8 scores 4*s - 2 of residues 0..3
     int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair
@@ -545,7 +546,14 @@ struct FastStrip {
             else if (j == 2) v.z = dw;
             else v.w = dw;
         }
-        if (in.store_dirs) dirq[(size_t)(kb >> 2) * 64] = v;
+        if (in.store_dirs) {
+            uint4 *p = dirq + (size_t)(kb >> 2) * 64;
+            if (!SINGLE && in.wt_dirs) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 vv = {v.x, v.y, v.z, v.w};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(vv) : "memory");
+            } else *p = v;
+        }
     }
 
     // folds the packed per-row candidates of the 2048-step chunk that starts at step `base` into the lane candidate

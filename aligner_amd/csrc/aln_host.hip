@@ -23,6 +23,7 @@
 
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
+extern "C" void aln_launch_traceback_overlap(const TraceArgs *a, uint32_t waves, hipStream_t s);
 extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s);
 extern "C" void aln_launch_traceback_expand_single(const TraceArgs *a, uint32_t pair, hipStream_t s);
@@ -74,6 +75,13 @@ struct aln_batch {
     PairDesc *d_descs = nullptr;
     uint32_t *d_order = nullptr;
     uint32_t *d_counter = nullptr;
+    // overlapped traceback (aln_batch_run): second stream, fork/join events, per-pair "walked in run #epoch" marks
+    bool overlap = false;
+    uint32_t tb_waves = 0, n_chunks = 0, epoch = 0;
+    size_t counter_bytes = 256;
+    uint32_t *d_walked = nullptr;
+    hipStream_t tb_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_dirs = nullptr;
     aln_pair_result *d_results = nullptr;
     uint8_t *d_tb = nullptr;
@@ -178,6 +186,10 @@ static void batch_free(aln_batch *b)
                     b->d_matrix, b->d_hmat, b->d_granules, b->d_advice1, b->d_cand, b->d_ctrl, b->d_tbmap, b->d_pwm_words};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (b->d_walked) (void)hipFree(b->d_walked);
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+    if (b->tb_stream) (void)hipStreamDestroy(b->tb_stream);
     delete b;
 }
 
@@ -329,6 +341,28 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     // ---- grid: persistent waves, 4 per workgroup
     const uint32_t wg_needed = (uint32_t)((b->n_small + 3) / 4);
     b->grid = std::max(1u, std::min(wg_needed, (uint32_t)ctx->cus * 4u));
+    // Overlapped traceback: worth it when the fill keeps every CU busy for a while.  The fast fill kernel holds 3 workgroups
+    // per CU (168 VGPRs x 3 waves per SIMD leave no room for anything else), so the grid stops `reserve` workgroups short of
+    // that (env ALN_TB_OVERLAP, 0 = off): on those CUs the walk kernel's waves (32 VGPRs, no LDS) fit beside the fill, 20 per CU.
+    {
+        const uint32_t outs = p->outputs ? p->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
+        const uint32_t resident = (uint32_t)ctx->cus * 3u;
+        // Each reserved slot costs the fill 1/resident of its rate and the walk kernel needs ~30 of them to keep up, so the
+        // overlap pays while the walks' latency floor (~1.5 ms for 2000-residue pairs) is more than ~4 % of the step:
+        // measured on C5 shards, 12.5k / 25k / 50k pairs gain 7 / 4 / 1 %, the full 100k pairs (49 ms) lose 0.6 %.
+        uint64_t queue_cells = 0;
+        for (size_t i = 0; i < b->n_small; ++i) queue_cells += (uint64_t)b->descs[order[i]].N * b->descs[order[i]].M;
+        const char *e = getenv("ALN_TB_OVERLAP");
+        const uint32_t reserve = e ? (uint32_t)atoi(e) : (queue_cells <= 80000000000ull ? (uint32_t)ctx->cus / 8u : 0u);
+        b->overlap = b->fast && b->is_int && (outs & ALN_OUT_TRACEBACK) && reserve > 0 && reserve < resident &&
+                     b->n_small >= 4096 && wg_needed >= resident;
+        if (b->overlap) {
+            b->grid = resident - reserve;
+            b->tb_waves = reserve * 20u;
+            b->n_chunks = (uint32_t)((b->n_small + 63) / 64);
+            b->counter_bytes = 256 + 4ull * b->n_small;
+        }
+    }
     const uint64_t sc_size = b->is_int ? 4 : 8;
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
@@ -354,7 +388,14 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     BCHK(dmalloc((void **)&b->d_seqs, seq_bytes + 64));
     BCHK(dmalloc((void **)&b->d_descs, n * sizeof(PairDesc)));
     BCHK(dmalloc((void **)&b->d_order, n * sizeof(uint32_t)));
-    BCHK(dmalloc((void **)&b->d_counter, 256));
+    BCHK(dmalloc((void **)&b->d_counter, b->counter_bytes));
+    if (b->overlap) {
+        BCHK(dmalloc((void **)&b->d_walked, 4ull * n));
+        BCHK(hipMemset(b->d_walked, 0, 4ull * n));
+        BCHK(hipStreamCreateWithFlags(&b->tb_stream, hipStreamNonBlocking));
+        BCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        BCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    }
     BCHK(dmalloc((void **)&b->d_dirs, dir_total));
     BCHK(dmalloc((void **)&b->d_results, n * sizeof(aln_pair_result)));
     BCHK(dmalloc((void **)&b->d_tb, tb_total));
@@ -425,7 +466,7 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     hipStream_t s = stream ? (hipStream_t)stream : b->ctx->stream;
     b->last_stream = s;
     if (b->n == 0) return ALN_OK;
-    HIPCHK(hipMemsetAsync(b->d_counter, 0, 256, s));
+    HIPCHK(hipMemsetAsync(b->d_counter, 0, b->counter_bytes, s));
     FillArgs fa{};
     fa.seqs = b->d_seqs; fa.descs = b->d_descs; fa.order = b->d_order; fa.n_pairs = (uint32_t)b->n_small;
     fa.counter = b->d_counter; fa.dirs = b->d_dirs; fa.results = b->d_results;
@@ -442,10 +483,28 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
     if (ev) HIPCHK(hipEventRecord(ev[0], s));
     b->fill_launches = 0;
+    const uint32_t outs = b->params.outputs ? b->params.outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
+    TraceArgs ta{};
+    ta.seqs = b->d_seqs; ta.descs = b->d_descs; ta.n_pairs = (uint32_t)b->n; ta.dirs = b->d_dirs;
+    ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code; ta.pwm = b->pwm ? 1 : 0;
+    const bool overlap = b->overlap && b->store_dirs && (outs & ALN_OUT_TRACEBACK);
+    if (overlap) {
+        fa.doneq = b->d_counter + 64;
+        ta.walked = b->d_walked; ta.epoch = ++b->epoch; ta.n_order = (uint32_t)b->n_small;
+        ta.doneq = b->d_counter + 64; ta.head = b->d_counter + 2; ta.wait_ticks = 50000000ull;          // 0.5 s
+        if (const char *w = getenv("ALN_TB_WAIT_US")) ta.wait_ticks = 100ull * strtoull(w, nullptr, 10);   // testing: 0 = give up at once
+        HIPCHK(hipEventRecord(b->ev_fork, s));                               // after the memset, before the fill
+    }
     if (b->n_small) {
         aln_launch_fill(&fa, b->is_int ? 1 : 0, b->fast ? 1 : 0, b->grid, b->lds_bytes, s);
         HIPCHK(hipGetLastError());
         b->fill_launches = 1;
+    }
+    if (overlap) {                                                           // submitted after the fill, runs beside it
+        HIPCHK(hipStreamWaitEvent(b->tb_stream, b->ev_fork, 0));
+        aln_launch_traceback_overlap(&ta, b->tb_waves, b->tb_stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(b->ev_join, b->tb_stream));
     }
     for (size_t j = 0; j < b->single_pairs.size(); ++j) {
         const PairDesc &d = b->descs[b->single_pairs[j]];
@@ -474,11 +533,8 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
         HIPCHK(hipGetLastError());
     }
     if (ev) HIPCHK(hipEventRecord(ev[1], s));
-    const uint32_t outs = b->params.outputs ? b->params.outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
     if ((outs & ALN_OUT_TRACEBACK) && b->store_dirs) {
-        TraceArgs ta{};
-        ta.seqs = b->d_seqs; ta.descs = b->d_descs; ta.n_pairs = (uint32_t)b->n; ta.dirs = b->d_dirs;
-        ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code; ta.pwm = b->pwm ? 1 : 0;
+        if (overlap) HIPCHK(hipStreamWaitEvent(s, b->ev_join, 0));
         aln_launch_traceback(&ta, s);       // every pair except those in the uniform-R layout (handled below)
         for (size_t j = 0; j < b->single_pairs.size(); ++j) {
             const PairDesc &d = b->descs[b->single_pairs[j]];

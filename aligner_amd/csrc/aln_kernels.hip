@@ -452,7 +452,7 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
 // lane state rejoins the checkpoint (localized repair); anything else escalates to full re-fills and finally to the
 // strict reference-order routine.
 template <int SEM, bool PWM>
-__device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairDesc &desc, aln_pair_result &res, int del, int ext)
+__device__ __forceinline__ bool do_pair_fast(FastIn in, const FillArgs &a, PairDesc &desc, aln_pair_result &res, int del, int ext)
 {
     const int lane = in.lane;
     const uint32_t N = desc.N, M = desc.M;
@@ -465,6 +465,7 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
     in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0;
     in.ck_mode = 0; in.last_flip = 0;
     in.store_dirs = a.store_dirs != 0;
+    in.wt_dirs = a.doneq != nullptr;
     in.pwm = a.pwm != 0;
     in.pwm_words = a.pwm_words;
     if (in.hazard)
@@ -525,26 +526,53 @@ __device__ __forceinline__ void do_pair_fast(FastIn in, const FillArgs &a, PairD
             desc.layout = ALN_LAYOUT_ROWMAJOR;
             write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, 1u, in.pwm);
         }
-        return;
+        return true;                                     // directions written with ordinary stores
     }
     if (is_local<SEM>()) reduce_best<SEM>(o);
     if (lane == 0) {
         desc.layout = ALN_LAYOUT_SKEW;
         write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)(o.corner >> 2), N, M, passes, 1u, in.pwm);
     }
+    return false;
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------- fill kernels: persistent waves over a work queue
-__device__ __forceinline__ bool next_pair(const FillArgs &a, int lane, uint32_t &pair)
+__device__ __forceinline__ bool next_pair(const FillArgs &a, int lane, uint32_t &pair, uint32_t &idx)
 {
-    uint32_t idx = 0;
+    idx = 0;
     if (lane == 0) idx = atomicAdd(a.counter, 1u);
     idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
     if (idx >= a.n_pairs) return false;
     pair = a.order[idx];
     return true;
+}
+// Overlapped traceback: this pair is complete -- hand it to the walk kernel.  The walk waves sit on other XCDs (own L2), and
+// an agent-scope release fence here would write back this XCD's whole L2 (~90 us per pair, measured as 6 % of the fill).
+// Instead everything a walk reads is stored write-through: the direction quads (FastIn::wt_dirs), and here the few
+// summary fields; then only the stores' completion is awaited before the queue entry (itself write-through) goes out.
+__device__ __forceinline__ void wt_store32(void *p, uint32_t v)
+{
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void pair_done(const FillArgs &a, int lane, uint32_t pair, bool plain_stores)
+{
+    if (!a.doneq) return;
+    if (plain_stores) __threadfence();                   // strict-order fallback / generic kernels: ordinary stores, full release
+    if (lane == 0) {
+        aln_pair_result &res = a.results[pair];
+        PairDesc &desc = a.descs[pair];
+        wt_store32(&res.status, (uint32_t)res.status);
+        wt_store32(&res.end_y, res.end_y);
+        wt_store32(&res.end_x, res.end_x);
+        wt_store32(&desc.layout, desc.layout);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const uint32_t pos = __hip_atomic_fetch_add(a.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.doneq + pos, pair + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 __device__ __forceinline__ void skip_invalid(aln_pair_result &res, int status, int lane)
 {
@@ -557,14 +585,13 @@ __device__ __forceinline__ void skip_invalid(aln_pair_result &res, int status, i
 // The SIMD's instruction arbiter is not fair: among waves of equal priority the oldest wave issues first, and with three
 // VALU-bound waves per SIMD the youngest gets ~13 % of the issue slots (measured: 1.5 / 0.9 / 0.35 GCUPS for the three).
 // Throughput does not care, the tail of a small batch does: a large pair taken at t = 0 by a youngest wave was still in its
-// first pass when everything else had finished.  So the wave's priority follows the size of its pair (quartiles of the
+// first pass when everything else had finished.  So the wave's priority follows the size of its pair (thirds of the
 // queue's largest pair): in the LPT order this is "oldest pair first" -- a large pair is never starved by the smaller pairs
 // the older waves of its SIMD move on to.
 __device__ __forceinline__ void set_wave_priority(uint64_t cells, uint64_t max_cells)
 {
-    if (4 * cells > 3 * max_cells) __builtin_amdgcn_s_setprio(3);
-    else if (2 * cells > max_cells) __builtin_amdgcn_s_setprio(2);
-    else if (4 * cells > max_cells) __builtin_amdgcn_s_setprio(1);
+    if (3 * cells > 2 * max_cells) __builtin_amdgcn_s_setprio(2);          // 3 belongs to the walk kernel that runs beside the fill
+    else if (3 * cells > max_cells) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 }
 
@@ -590,12 +617,13 @@ __global__ __launch_bounds__(256, 2) void aln_fill_kernel(FillArgs a)
     w.cols = a.cols;
     w.del = ScOps<SC>::from_double(a.del);
     w.ext = ScOps<SC>::from_double(a.ext);
-    uint32_t pair;
-    while (next_pair(a, w.lane, pair)) {
+    uint32_t pair, qpos;
+    while (next_pair(a, w.lane, pair, qpos)) {
         PairDesc &desc = a.descs[pair];
         aln_pair_result &res = a.results[pair];
-        if (desc.status != ALN_OK) { skip_invalid(res, desc.status, w.lane); continue; }
-        do_pair<SC, SEM>(w, a, desc, res);
+        if (desc.status != ALN_OK) skip_invalid(res, desc.status, w.lane);
+        else do_pair<SC, SEM>(w, a, desc, res);
+        pair_done(a, w.lane, pair, true);
     }
 }
 
@@ -626,13 +654,17 @@ __global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
     in.ne4 = -4 * (int)a.ext;
     in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr; in.qo_pad = nullptr; in.bring = nullptr;
     in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.adv_any = false; in.store_dirs = true; in.pwm = false; in.pwm_words = nullptr; in.ck_mode = 0; in.last_flip = 0;
-    uint32_t pair;
-    while (next_pair(a, in.lane, pair)) {
+    uint32_t pair, qpos;
+    while (next_pair(a, in.lane, pair, qpos)) {
         PairDesc &desc = a.descs[pair];
         aln_pair_result &res = a.results[pair];
-        if (desc.status != ALN_OK) { skip_invalid(res, desc.status, in.lane); continue; }
-        set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
-        do_pair_fast<SEM, PWM>(in, a, desc, res, (int)a.del, (int)a.ext);
+        bool plain = false;
+        if (desc.status != ALN_OK) skip_invalid(res, desc.status, in.lane);
+        else {
+            set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
+            plain = do_pair_fast<SEM, PWM>(in, a, desc, res, (int)a.del, (int)a.ext);
+        }
+        pair_done(a, in.lane, pair, plain);
     }
 }
 
@@ -869,10 +901,8 @@ __device__ __forceinline__ StripView strip_view(const uint8_t *dirs, const PairD
 // including the duplicated seed pair.  Pass 1 is the dependent chain -- one direction word per step, shifts only, the
 // 2-bit tags go to a scratch byte string; pass 2 turns the tags into the two aligned code strings, written in final
 // (forward) order, with loads whose addresses do not depend on loaded data.
-extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs a)
+__device__ __forceinline__ void tb_walk_pair(const TraceArgs &a, uint32_t pair)
 {
-    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= a.n_pairs) return;
     const PairDesc &d = a.descs[pair];
     aln_pair_result &res = a.results[pair];
     if (res.status != ALN_OK) return;
@@ -922,6 +952,49 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     }
     res.start_y = cy; res.start_x = cx;
     res.aln_len = len + (a.pwm ? 0u : 1u);              // + the duplicated seed pair (none for the PWM aligner)
+}
+extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs a)
+{
+    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= a.n_pairs) return;
+    if (a.walked && a.walked[pair] == a.epoch) return;  // the overlap kernel has been here
+    tb_walk_pair(a, pair);
+}
+// The walks are latency-bound and the fill is issue-bound: this kernel runs BESIDE the fill kernel (second stream; the host
+// leaves a few workgroup slots free for it) and walks the pairs in the order the fill finishes them: persistent waves, each
+// claims the next 64 entries of the fill's completion queue and waits for them to appear.  A wave that waits too long
+// gives up -- nothing depends on this kernel: aln_traceback_kernel runs after the fill and walks whatever is left, so a
+// runtime that serializes the two kernels (profilers do) only loses the overlap.
+extern "C" __global__ __launch_bounds__(64) void aln_traceback_overlap_kernel(TraceArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);       // latency-bound and light on issue slots: ahead of the fill waves it shares a SIMD with
+    for (;;) {
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = __hip_atomic_fetch_add(a.head, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= a.n_order) return;
+        // 64 consecutive entries of the completion queue: they fill within microseconds of each other
+        const uint32_t my = base + threadIdx.x;
+        uint32_t v = 0;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+            if (my < a.n_order && v == 0) v = __hip_atomic_load(a.doneq + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (__all(my >= a.n_order || v != 0)) break;
+            __builtin_amdgcn_s_sleep(127);
+            if (wall_clock64() - t0 > a.wait_ticks) return;
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);         // nothing cached here from before the entries appeared
+        if (my < a.n_order) {
+            tb_walk_pair(a, v - 1u);
+            a.walked[v - 1u] = a.epoch;
+        }
+    }
+}
+// one wave that sleeps ~30 us: queued in front of the overlap kernel so that the fill kernel's workgroups are placed first
+extern "C" __global__ __launch_bounds__(64) void aln_delay_kernel(uint32_t ticks)
+{
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
 // ---------------------------------------------------------------- parallel traceback of one large pair
@@ -1345,6 +1418,11 @@ extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
 {
     const uint32_t grid = (a->n_pairs + 63) / 64;
     hipLaunchKernelGGL(aln_traceback_kernel, dim3(grid), dim3(64), 0, s, *a);
+}
+extern "C" void aln_launch_traceback_overlap(const TraceArgs *a, uint32_t waves, hipStream_t s)
+{
+    hipLaunchKernelGGL(aln_delay_kernel, dim3(1), dim3(64), 0, s, 3000u);
+    hipLaunchKernelGGL(aln_traceback_overlap_kernel, dim3(waves), dim3(64), 0, s, *a);
 }
 extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s)
 {

@@ -588,3 +588,31 @@ def test_single_pair_traceback_outside_the_exit_map_band(orc, blosum62, sem):
     for q, t in ((np.concatenate([a, x, b]), np.concatenate([a, b])), (np.concatenate([a, b]), np.concatenate([a, x, b]))):
         res = check_pair(orc, sem, q, t, 11, 2, blosum62, full=False)
         assert res.flags & 2 and res.aln_len > 2900
+
+
+def test_overlapped_traceback_batch(orc, blosum62):
+    """A batch large enough (>= 4096 pairs) for the walk kernel to run beside the fill kernel: every summary and both
+    strings against the oracle, and a second run of the same staged batch (new epoch of the "walked" marks) repeats them."""
+    b = workloads.c5_batch(n_pairs=5000, lo=30, hi=260)
+    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    from aligner_amd.batch import StagedBatch
+    sb = StagedBatch(b, _ffi.CORE_LOCAL, 11, 2, blosum62, outputs=_ffi.OUT_SCORE | _ffi.OUT_TRACEBACK)
+    for _ in range(3):
+        sb.run()
+    sb.sync()
+    again = sb.fetch(want_traceback=True)
+    assert (again.results == got.results).all()
+    for i in range(0, len(b), 97):
+        qa, ta = got.aligned(i)
+        qb, tb = again.aligned(i)
+        assert (qa == qb).all() and (ta == tb).all()
+
+
+def test_overlapped_traceback_gives_up_cleanly(orc, blosum62, monkeypatch):
+    """The walk kernel that runs beside the fill may give up on a wait (ALN_TB_WAIT_US=0: at the first entry that is not
+    there yet); the sweep after the fill walks what it left, and the results do not change."""
+    monkeypatch.setenv("ALN_TB_WAIT_US", "0")
+    b = workloads.c5_batch(n_pairs=4500, lo=30, hi=200)
+    _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    monkeypatch.setenv("ALN_TB_OVERLAP", "0")
+    _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
