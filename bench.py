@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=100000, help="size of the C5 batch (default: the full 100 000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="world size 1 only: run the RCCL process group and the summary gather of the N > 1 path anyway")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     args = ap.parse_args()
 
@@ -79,8 +81,10 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     n_gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.rehearse_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     S = get_blosum62()
@@ -100,19 +104,19 @@ def main():
     t_stage = time.perf_counter() - t_stage
     stream = torch.cuda.Stream()
     rec = RESULT_DTYPE.itemsize
-    if world > 1:
+    if use_dist:
         gather = SummaryGather([len(s) for s in shards], rank, "cuda")
         view = device_bytes_as_tensor(sb.results_device_ptr, len(batch) * rec)
 
     def step():
         with torch.cuda.stream(stream):
             sb.run(stream.cuda_stream)
-            if world > 1:
+            if use_dist:
                 gather(view)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -125,7 +129,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -140,7 +144,7 @@ def main():
     del fetched
     ok = int((res["status"] == 0).sum())
     refills = int((res["passes"] > 1).sum())
-    if world > 1:
+    if use_dist:
         everyone = gather.unpack(shards, args.pairs)
         assert (everyone[mine] == res).all() and int((everyone["status"] == 0).sum()) >= ok
 
@@ -214,7 +218,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     sb.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
