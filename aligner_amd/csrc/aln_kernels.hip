@@ -923,27 +923,47 @@ __device__ __forceinline__ void tb_walk_pair(const TraceArgs &a, uint32_t pair)
             cy -= (dd != D_LEFT); cx -= (dd != D_TOP);
         }
     } else {
-        StripView sv = strip_view(a.dirs, d, cy != 0 ? cy : 1u);
-        // The walk is one dependent load per step, and every miss is a trip to HBM (the direction store is tens of GB).
-        // A lane's quad (4 blocks, 16 B) covers 64/R consecutive steps of R rows: a path that moves up/left stays in
-        // it for several steps, so the last quad is kept in registers and only a change of quad loads.
-        const uint4 *qcur = nullptr;
-        uint4 quad = make_uint4(0, 0, 0, 0);
-        while (cy != 0 && cx != 0) {
-            if (cy - 1 - sv.y0 >= (64u << sv.lgR)) sv = strip_view(a.dirs, d, cy);   // the walk left the strip (upwards)
-            const uint32_t i = cy - 1 - sv.y0, lgR = sv.lgR, R = 1u << lgR, sh = 4u - lgR;
-            const uint32_t lane = i >> lgR, r = i & (R - 1u);
-            const uint32_t k = cx - 1 + lane, kb = k >> sh;
-            const uint4 *qp = reinterpret_cast<const uint4 *>(sv.wbase) + ((uint64_t)(kb >> 2) * 64u + lane);
-            if (qp != qcur) { quad = *qp; qcur = qp; }
-            const uint32_t sel = kb & 3u;
-            const uint32_t word = sel == 0 ? quad.x : sel == 1 ? quad.y : sel == 2 ? quad.z : quad.w;
-            const uint32_t bend = (kb << sh) + (1u << sh) - 1u, lend = lane + N - 1u;
-            const uint32_t e = min(bend, lend);
-            const uint32_t tag = (word >> (30u - 2u * (((e - k) << lgR) + (R - 1u - r)))) & 3u;
-            if (tag == 3u) break;                       // Beginning
-            ops[len++] = (uint8_t)tag;
-            cy -= (tag != 1u); cx -= (tag != 2u);       // 0 Diagonal, 1 Left, 2 Top
+        // The walk is one dependent chain: ~a quarter of a load per step (a lane's quad -- 4 blocks, 16 B -- covers 64/R
+        // consecutive steps of R rows and stays in registers until the path leaves it) and the instructions between two
+        // loads, which a lone wave issues at one per ~4.6 cycles.  So the step is kept short: the state is (row within the
+        // strip, column - 1), both signed -- one sign test catches "left the strip upwards" and both borders --, and the
+        // tag's position in the quad is 2 * ((k mod 64/R) * R + r): within a block the words fill from bit 0 upwards in
+        // step-major order (aln_dir_bitpos), except in a lane's last, right-aligned block (shift by R per missing step).
+        if (cy != 0 && cx != 0) {
+            StripView sv = strip_view(a.dirs, d, cy);
+            int iy = (int)(cy - 1 - sv.y0), cxm = (int)cx - 1;
+            uint32_t lgR = sv.lgR, rmask = (1u << lgR) - 1u, qsh = 6u - lgR, kqmask = (1u << qsh) - 1u, bmask = (16u >> lgR) - 1u;
+            const uint4 *wq = reinterpret_cast<const uint4 *>(sv.wbase);
+            const uint32_t Nm1 = N - 1u;
+            uint32_t qcur = 0xffffffffu;
+            uint4 quad = make_uint4(0, 0, 0, 0);
+            uint8_t *p = ops;
+            for (;;) {
+                if ((iy | cxm) < 0) {                       // above the strip, or a border
+                    cy = (uint32_t)(iy + 1) + sv.y0; cx = (uint32_t)(cxm + 1);
+                    if (cy == 0 || cx == 0) break;
+                    sv = strip_view(a.dirs, d, cy);
+                    iy = (int)(cy - 1 - sv.y0);
+                    lgR = sv.lgR; rmask = (1u << lgR) - 1u; qsh = 6u - lgR; kqmask = (1u << qsh) - 1u; bmask = (16u >> lgR) - 1u;
+                    wq = reinterpret_cast<const uint4 *>(sv.wbase);
+                    qcur = 0xffffffffu;
+                }
+                const uint32_t lane = (uint32_t)iy >> lgR, r = (uint32_t)iy & rmask;
+                const uint32_t k = (uint32_t)cxm + lane;
+                const uint32_t qi = ((k >> qsh) << 6) + lane;
+                if (qi != qcur) { quad = wq[qi]; qcur = qi; }
+                const uint32_t lend = lane + Nm1;
+                const uint32_t idx = (((k & kqmask) << lgR) | r) + ((max(k | bmask, lend) - lend) << lgR);
+                const uint64_t half = (idx & 32u) ? (((uint64_t)quad.w << 32) | quad.z) : (((uint64_t)quad.y << 32) | quad.x);
+                const uint32_t tag = (uint32_t)(half >> ((2u * idx) & 63u)) & 3u;
+                if (tag == 3u) {                            // Beginning
+                    cy = (uint32_t)(iy + 1) + sv.y0; cx = (uint32_t)(cxm + 1);
+                    break;
+                }
+                *p++ = (uint8_t)tag;
+                iy -= (tag != 1u); cxm -= (tag != 2u);      // 0 Diagonal, 1 Left, 2 Top
+            }
+            len = (uint32_t)(p - ops);
         }
         if (global) {                                   // borders: D[0][x] = Left, D[y][0] = Top (simple/mod.rs:59-67)
             while (cx != 0 && cy == 0) { ops[len++] = 1; cx--; }
