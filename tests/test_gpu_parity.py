@@ -616,3 +616,18 @@ def test_overlapped_traceback_gives_up_cleanly(orc, blosum62, monkeypatch):
     _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
     monkeypatch.setenv("ALN_TB_OVERLAP", "0")
     _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+
+
+def test_pwm_window_batch_with_overlapped_traceback(orc):
+    """5000 short windows against one PWM: enough pairs for the walk kernel to run beside the fill (PWM tag strings sit
+    behind the u32 column numbers, and a window without a positive cell has no walk at all)."""
+    from aligner_amd.pwm import align_windows
+    rng = np.random.default_rng(4242)
+    pwm = rng.integers(-2, 3, (4, 48)).astype(np.float64)
+    chrom = rng.integers(0, 4, 60000).astype(np.uint8)
+    wins = [chrom[i * 11:i * 11 + int(rng.integers(5, 140))] for i in range(5000)]
+    res, alns = align_windows(wins, 3, 1, pwm)
+    for i in range(0, 5000, 3):
+        ref = orc.align_pwm(wins[i], 3, 1, pwm)
+        assert res["f"][i] == ref["f"] and alns[i].coords == ref["coords"], i
+        assert alns[i].numbered.tolist() == ref["numbered"].tolist() and alns[i].query.tolist() == ref["qal"].tolist(), i
