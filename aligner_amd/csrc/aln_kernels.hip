@@ -1301,28 +1301,42 @@ extern "C" __global__ __launch_bounds__(256) void aln_traceback_expand_kernel(Tr
     const uint8_t *__restrict__ ops = a.tb + d.tb_off + (a.pwm ? 5ull : 2ull) * cap;
     uint32_t *__restrict__ numbered = reinterpret_cast<uint32_t *>(qa);    // PWM: column numbers instead of query residues
     const uint32_t len = res.aln_len - (a.pwm ? 0u : 1u);
-    // output positions j in [lo, hi) belong to this lane; position j reads ops[len - 1 - j]
-    const uint32_t per = (len + 63) / 64;
-    const uint32_t lo = min(len, (uint32_t)lane * per), hi = min(len, lo + per);
-    uint32_t dy = 0, dx = 0;
-    for (uint32_t j = lo; j < hi; ++j) {
-        const uint32_t tag = ops[len - 1 - j];
-        dx += (tag != 2u); dy += (tag != 1u);
-    }
-    // exclusive wave scan of (dy, dx)
-    uint32_t sy = dy, sx = dx;
+    // Position j reads ops[len - 1 - j] and needs the number of moves in x / y among positions 0..j: lane l takes position
+    // j0 + l, so tags, residues and both strings move in coalesced lines, the prefix counts come from two ballots, and four
+    // such groups are in flight at once -- the loads of a group do not depend on the group before (a lane-contiguous split
+    // was one dependent byte load per position: 2 x 35 round trips per pair).
+    uint32_t base_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.start_y);
+    uint32_t base_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.start_x);
+    for (uint32_t j0 = 0; j0 < len; j0 += 256u) {
+        uint32_t tag[4], px[4], py[4];
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint32_t oy = (uint32_t)__shfl_up((int)sy, m), ox = (uint32_t)__shfl_up((int)sx, m);
-        if (lane >= m) { sy += oy; sx += ox; }
-    }
-    uint32_t py = res.start_y + sy - dy, px = res.start_x + sx - dx;
-    for (uint32_t j = lo; j < hi; ++j) {
-        const uint32_t tag = ops[len - 1 - j];
-        px += (tag != 2u); py += (tag != 1u);           // the cell this step left
-        if (a.pwm) numbered[j] = (tag == 2u) ? 0u : px;                    // pwm/mod.rs:86-101
-        else qa[j] = (tag == 2u) ? a.blank : q[px - 1];
-        ta[j] = (tag == 1u) ? a.blank : t[py - 1];
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + 64u * u + (uint32_t)lane;
+            tag[u] = (j < len) ? (uint32_t)ops[len - 1 - j] : 3u;      // 3: beyond the end, moves nothing
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool fx = (tag[u] != 2u) && (tag[u] != 3u), fy = (tag[u] != 1u) && (tag[u] != 3u);
+            const uint64_t bx = __ballot(fx), by = __ballot(fy);
+            px[u] = base_x + __builtin_amdgcn_mbcnt_hi((uint32_t)(bx >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bx, 0u)) + (fx ? 1u : 0u);
+            py[u] = base_y + __builtin_amdgcn_mbcnt_hi((uint32_t)(by >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)by, 0u)) + (fy ? 1u : 0u);
+            base_x += (uint32_t)__popcll(bx); base_y += (uint32_t)__popcll(by);
+        }
+        uint32_t qv[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                   // the cell this step left: (py, px)
+            qv[u] = (tag[u] == 2u || tag[u] == 3u) ? (uint32_t)a.blank : (a.pwm ? px[u] : (uint32_t)q[px[u] - 1]);
+            tv[u] = (tag[u] == 1u || tag[u] == 3u) ? (uint32_t)a.blank : (uint32_t)t[py[u] - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = j0 + 64u * u + (uint32_t)lane;
+            if (j < len) {
+                if (a.pwm) numbered[j] = (tag[u] == 2u) ? 0u : px[u];  // pwm/mod.rs:86-101
+                else qa[j] = (uint8_t)qv[u];
+                ta[j] = (uint8_t)tv[u];
+            }
+        }
     }
     if (lane == 0 && !a.pwm) {
         qa[len] = q[res.end_x - 1];                     // simple/mod.rs:102-105, :213-216: the duplicated seed
