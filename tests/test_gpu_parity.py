@@ -631,3 +631,31 @@ def test_pwm_window_batch_with_overlapped_traceback(orc):
         ref = orc.align_pwm(wins[i], 3, 1, pwm)
         assert res["f"][i] == ref["f"] and alns[i].coords == ref["coords"], i
         assert alns[i].numbered.tolist() == ref["numbered"].tolist() and alns[i].query.tolist() == ref["qal"].tolist(), i
+
+
+def test_c5_full_batch_against_oracle_digest(blosum62):
+    """BASELINE C5 at FULL size (100 000 pairs, 1.2e11 cells): every score, and per block of 1000 pairs a SHA-256 over the
+    summaries (score, end, start, length) and both aligned strings, against tests/golden/c5_100k_digest.npz -- generated by
+    the CPU oracle (tests/golden/make_c5_golden.py, ~10 min on 8 cores), so the whole headline workload is bit-exact."""
+    import hashlib
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c5_100k_digest.npz"))
+    block = int(g["block"])
+    b = workloads.c5_batch(100000)
+    got = align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    r = got.results
+    assert (r["status"] == 0).all()
+    assert (r["score"].astype(np.int64) == g["scores"]).all()
+    bad = []
+    for k in range(len(b) // block):
+        h = hashlib.sha256()
+        lo = k * block
+        summ = np.stack([r[f][lo:lo + block].astype(np.int32) for f in ("score", "end_y", "end_x", "start_y", "start_x", "aln_len")], axis=1)
+        h.update(np.ascontiguousarray(summ).tobytes())
+        for i in range(lo, lo + block):
+            qa, ta = got.aligned(i)
+            h.update(np.ascontiguousarray(qa, dtype=np.uint8).tobytes())
+            h.update(np.ascontiguousarray(ta, dtype=np.uint8).tobytes())
+        if h.digest() != g["digests"][k].tobytes():
+            bad.append(k)
+    assert not bad, "blocks with a different digest: %s" % bad[:10]

@@ -178,3 +178,31 @@ def test_generated_asm_is_in_sync_with_its_generator(tmp_path):
                 body = body[:body.index("\n\n")]
                 got = [ln.strip().rstrip("\\").strip().strip('"').replace("\\n\\t", "") for ln in body.splitlines()[1:]]
                 assert got == lines, name
+
+
+def test_c5_digest_fixture_is_the_oracles():
+    """tests/golden/c5_100k_digest.npz (what the GPU suite checks the full C5 batch against) really is the CPU oracle's
+    output: one block of 1000 pairs is regenerated here (make_c5_golden.py made all 100)."""
+    import importlib.util
+    import os
+    import oracle as orc
+    from aligner_amd import workloads
+    from aligner_amd.matrices import get_blosum62
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_c5_golden", os.path.join(here, "golden", "make_c5_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(here, "golden", "c5_100k_digest.npz"))
+    k = 57
+    b = workloads.c5_batch(100000, indices=np.arange(k * 1000, (k + 1) * 1000))
+    ref, tb, tb_off = orc.align_batch(orc.CORE_LOCAL, b.seqs, b.q_off, b.q_len, b.t_off, b.t_len, 11, 2, get_blosum62(), n_threads=8)
+    summ = np.zeros((1000, 6), dtype=np.int32)
+    strings = []
+    for i in range(1000):
+        r = ref[i]
+        summ[i] = (int(r.score), r.end_y, r.end_x, r.start_y, r.start_x, r.aln_len)
+        cap = int(b.q_len[i] + b.t_len[i]) + 2
+        o = int(tb_off[i])
+        strings.append((tb[o:o + r.aln_len], tb[o + cap:o + cap + r.aln_len]))
+    assert mk.block_digest(summ, strings) == g["digests"][k].tobytes()
+    assert (summ[:, 0] == g["scores"][k * 1000:(k + 1) * 1000]).all()
