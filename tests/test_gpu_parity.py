@@ -659,3 +659,9 @@ def test_c5_full_batch_against_oracle_digest(blosum62):
         if h.digest() != g["digests"][k].tobytes():
             bad.append(k)
     assert not bad, "blocks with a different digest: %s" % bad[:10]
+
+
+def test_c3_full_batch_matches_oracle(orc):
+    """BASELINE C3 at full size (10 000 read pairs of 150 bp, core global, +5/-4, 10/1): every summary and both strings
+    against the oracle run on the same batch (2.3e8 cells: seconds on the host)."""
+    _check_batch(orc, workloads.c3_batch(10000), _ffi.CORE_GLOBAL, 10, 1, nucleotide_matrix())
