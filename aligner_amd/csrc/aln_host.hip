@@ -77,7 +77,7 @@ struct aln_batch {
     uint32_t *d_counter = nullptr;
     // overlapped traceback (aln_batch_run): second stream, fork/join events, per-pair "walked in run #epoch" marks
     bool overlap = false;
-    uint32_t tb_waves = 0, n_chunks = 0, epoch = 0;
+    uint32_t tb_waves = 0, epoch = 0;
     size_t counter_bytes = 256;
     uint32_t *d_walked = nullptr;
     hipStream_t tb_stream = nullptr;
@@ -341,25 +341,21 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
     // ---- grid: persistent waves, 4 per workgroup
     const uint32_t wg_needed = (uint32_t)((b->n_small + 3) / 4);
     b->grid = std::max(1u, std::min(wg_needed, (uint32_t)ctx->cus * 4u));
-    // Overlapped traceback: worth it when the fill keeps every CU busy for a while.  The fast fill kernel holds 3 workgroups
-    // per CU (168 VGPRs x 3 waves per SIMD leave no room for anything else), so the grid stops `reserve` workgroups short of
-    // that (env ALN_TB_OVERLAP, 0 = off): on those CUs the walk kernel's waves (32 VGPRs, no LDS) fit beside the fill, 20 per CU.
+    // Overlapped traceback (aln_batch_run): the walk kernel runs beside the fill.  The fast fill kernel is built for 160 VGPRs,
+    // three workgroups per CU, so that every SIMD keeps 32 registers free: exactly one wave of the walk kernel (32 VGPRs, no
+    // LDS).  ALN_TB_OVERLAP: unset = one walk wave per SIMD beside a full fill grid; 0 = off; n > 0 = the earlier scheme (the
+    // fill grid stops n workgroups short of residency and the walk waves crowd onto those CUs, 20 per slot).
     {
         const uint32_t outs = p->outputs ? p->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
         const uint32_t resident = (uint32_t)ctx->cus * 3u;
-        // Each reserved slot costs the fill 1/resident of its rate and the walk kernel needs ~30 of them to keep up, so the
-        // overlap pays while the walks' latency floor (~1.5 ms for 2000-residue pairs) is more than ~4 % of the step:
-        // measured on C5 shards, 12.5k / 25k / 50k pairs gain 7 / 4 / 1 %, the full 100k pairs (49 ms) lose 0.6 %.
-        uint64_t queue_cells = 0;
-        for (size_t i = 0; i < b->n_small; ++i) queue_cells += (uint64_t)b->descs[order[i]].N * b->descs[order[i]].M;
         const char *e = getenv("ALN_TB_OVERLAP");
-        const uint32_t reserve = e ? (uint32_t)atoi(e) : (queue_cells <= 80000000000ull ? (uint32_t)ctx->cus / 8u : 0u);
-        b->overlap = b->fast && b->is_int && (outs & ALN_OUT_TRACEBACK) && reserve > 0 && reserve < resident &&
+        const uint32_t reserve = e ? (uint32_t)atoi(e) : 0u;
+        const bool off = e && reserve == 0;
+        b->overlap = !off && b->fast && b->is_int && (outs & ALN_OUT_TRACEBACK) && reserve < resident &&
                      b->n_small >= 4096 && wg_needed >= resident;
         if (b->overlap) {
             b->grid = resident - reserve;
-            b->tb_waves = reserve * 20u;
-            b->n_chunks = (uint32_t)((b->n_small + 63) / 64);
+            b->tb_waves = reserve ? reserve * 20u : (uint32_t)ctx->cus * 4u;
             b->counter_bytes = 256 + 4ull * b->n_small;
         }
     }

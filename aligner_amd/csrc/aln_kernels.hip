@@ -628,7 +628,10 @@ __global__ __launch_bounds__(256, 2) void aln_fill_kernel(FillArgs a)
 }
 
 template <int SEM, bool PWM>
-__global__ __launch_bounds__(256, 3) void aln_fill_fast_kernel(FillArgs a)
+// 160 VGPRs, not the 168 that three waves per SIMD would allow (the attribute counts pairs on gfx90a+): the 32 registers
+// left over on every SIMD hold one wave of the walk kernel that runs beside the fill.
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(3, 3), amdgpu_num_vgpr(80)))
+void aln_fill_fast_kernel(FillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *S = reinterpret_cast<int *>(smem);
@@ -985,7 +988,7 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
 // claims the next 64 entries of the fill's completion queue and waits for them to appear.  A wave that waits too long
 // gives up -- nothing depends on this kernel: aln_traceback_kernel runs after the fill and walks whatever is left, so a
 // runtime that serializes the two kernels (profilers do) only loses the overlap.
-extern "C" __global__ __launch_bounds__(64) void aln_traceback_overlap_kernel(TraceArgs a)
+extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_num_vgpr(16))) void aln_traceback_overlap_kernel(TraceArgs a)
 {
     __builtin_amdgcn_s_setprio(3);       // latency-bound and light on issue slots: ahead of the fill waves it shares a SIMD with
     for (;;) {
