@@ -66,6 +66,12 @@ def main():
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line.  Libraries print there too (RCCL writes a five-line version banner to fd 1 when the
+    # process group comes up), so fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from aligner_amd import _ffi, runtime, workloads
@@ -216,7 +222,7 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, S)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     sb.close()
     if use_dist:
         dist.destroy_process_group()
