@@ -1,4 +1,4 @@
-// aln_fast.cuh -- the fast integer fill path (included by aln_kernels.hip inside its anonymous namespace).
+// aln_fast.h -- the fast integer fill path (included by aln_kernels.hip inside its anonymous namespace).
 //
 // Same recurrence as the generic path, reformulated so that ONE v_max3_i32 yields value AND direction:
 //   carried state   T = 4*H + 2                              (H exact in the upper 30 bits)

@@ -292,7 +292,7 @@ __device__ __noinline__ void serial_fill_impl(Wave<SC> &w)
     w.corner = col[M];
 }
 
-#include "aln_fast.cuh"
+#include "aln_fast.h"
 
 // The per-wave state must stay in registers on the hot path: the out-of-line serial routine gets its own copy so the
 // caller's Wave object never has its address taken.

@@ -8,7 +8,8 @@ samples).  Here the 4 999 shuffled targets are packed once and scored by ONE sco
 parity for this function is statistical; parity of the scores for given shuffles is bit-exact and tested).
 
 The extreme-value fit that turns the scores into a p-value (statistics/mod.rs:36-238) is host numerics in the
-reference as well; it is restated in numpy below so that calculate_p_value is a complete drop-in.
+reference as well; it is restated in numpy below (including the loop-scoped re-binding of k / lambda at :69) and pinned
+by tests/test_host_logic.py against an independent scalar restatement (tests/pyref.py).
 """
 import numpy as np
 
@@ -140,8 +141,12 @@ def calculate_distribution_params(query_length, target_lengths, scores):
         k = n / (nn * np.exp(-lam * s_all)).sum()
         ll = n * np.log(lam * k) + (np.log(nn) - lam * s_all - k * nn * np.exp(-lam * s_all)).sum()
         t_act, s_act = t_all.copy(), s_all.copy()
+        # statistics/mod.rs:69: `let (k, lambda) = estimate_..(.., k, lambda, h)` SHADOWS inside the loop body, so every
+        # iteration restarts the Newton step from the initial moment estimates k0 / lam0 (only h and the active subset
+        # carry over), and the fall-through Ok(..) after MAXITER (:122) returns k0 / lam0 with the last h.
+        k0, lam0 = k, lam
         for _ in range(MAXITER + 1):
-            k, lam = _estimate_k_and_lambda(query_length, t_act, s_act, k, lam, h)
+            k, lam = _estimate_k_and_lambda(query_length, t_act, s_act, k0, lam0, h)
             h = _estimate_h(query_length, t_act, s_act, k, lam, h)
             nn = _nn(query_length, t_all, k, h)
             ll_new = n * np.log10(lam * k) + (np.log10(nn) - lam * s_all - k * nn * np.exp(-lam * s_all)).sum()
@@ -150,9 +155,7 @@ def calculate_distribution_params(query_length, target_lengths, scores):
             ll = ll_new
             keep = n * (1.0 - np.exp(-k * nn * np.exp(-lam * s_all))) >= 1.0
             t_act, s_act = t_all[keep], s_all[keep]
-            if len(t_act) == 0:
-                break
-    return DistributionParams(k, lam, h)
+    return DistributionParams(k0, lam0, h)
 
 
 def calculate_p_value(query, target, initial_score, del_, ins, matrix, rng=None, device=None):

@@ -31,13 +31,11 @@ def _synth_ranges(seed, alphabet_size, src_off, dst_off, lens, out):
     """out[dst_off[j] + k] = splitmix64(seed) output (src_off[j] + k) % A -- native helper (csrc/aln_synth.c)."""
     import ctypes as C
     import os
-    import subprocess
-    here = os.path.dirname(os.path.abspath(__file__))
-    lib = os.path.join(here, "lib", "libaln_synth.so")
-    src = os.path.join(here, "csrc", "aln_synth.c")
-    if not os.path.exists(lib) or os.path.getmtime(src) > os.path.getmtime(lib):
-        os.makedirs(os.path.dirname(lib), exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", lib, src])
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaln_synth.so")
+    if not os.path.exists(lib):
+        # built by aligner_amd/build.py (__graft_entry__.build()) before anything touches the GPU -- never compiled here:
+        # under torch.distributed.run N ranks would race on the same output file
+        raise ImportError("aligner_amd: %s is missing -- run `python -m aligner_amd.build`" % lib)
     src_off = np.ascontiguousarray(src_off, dtype=np.int64)
     dst_off = np.ascontiguousarray(dst_off, dtype=np.int64)
     lens = np.ascontiguousarray(lens, dtype=np.int64)

@@ -130,3 +130,121 @@ def pwm(seq, dele, ext, M):
             numbered.append(cx); qal.append(seq[cy - 1]); cx -= 1; cy -= 1
     return dict(H=H, D=Dm, numbered=numbered[::-1], qal=qal[::-1], f=max(H.values()),
                 coords=((cx + 1, best[1] + 1), (cy + 1, best[0] + 1)))
+
+
+# ---- statistics/mod.rs:36-238 walked by hand with scalar math (lists and math.*, no numpy), keeping the Rust scoping: the
+# `let (k, lambda) = ...` at :69 lives only inside one loop iteration, so the call's arguments are always the OUTER k, lambda.
+import math
+
+
+def _fexp(x):
+    try:
+        return math.exp(x)
+    except OverflowError:
+        return math.inf
+
+
+def _flog(x, base10=False):
+    if x != x:
+        return math.nan
+    if x < 0:
+        return math.nan
+    if x == 0:
+        return -math.inf
+    if x == math.inf:
+        return math.inf
+    return math.log10(x) if base10 else math.log(x)
+
+
+def _fdiv(a, b):
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a != a or a == 0:
+            return math.nan
+        return math.copysign(math.inf, a) * math.copysign(1.0, b)
+
+
+def _evd_nn(ql, ts, k, h):
+    out = []
+    for t in ts:
+        l = _fdiv(_flog(k * ql * t), h)
+        out.append((ql - l) * (t - l))
+    return out
+
+
+def _evd_k_lambda(ql, ts, sc, old_k, old_lambda, h, maxiter=10000, thr=1e-4):
+    k, lam = old_k, old_lambda
+    n = float(len(ts))
+    nn = _evd_nn(ql, ts, k, h)
+    es = [_fexp(-lam * s) for s in sc]
+    ssum = math.fsum(a * b for a, b in zip(nn, es)) if nn else 0.0
+    wsum = math.fsum(a * s * b for a, s, b in zip(nn, sc, es)) if nn else 0.0
+    for _ in range(maxiter + 1):
+        f = _fdiv(1.0, lam) - _fdiv(sum(sc), n) + _fdiv(wsum, ssum)
+        fd = -_fdiv(1.0, lam * lam) - _fdiv(sum(a * s * s * b for a, s, b in zip(nn, sc, es)), ssum) + _fdiv(wsum, ssum) ** 2
+        if not math.isfinite(f) or not math.isfinite(fd):
+            return k, lam
+        new_lam = lam - _fdiv(f, fd)
+        es = [_fexp(-lam * s) for s in sc]
+        ssum = sum(a * b for a, b in zip(nn, es))
+        wsum = sum(a * s * b for a, s, b in zip(nn, sc, es))
+        new_k = _fdiv(n, ssum)
+        if not math.isfinite(new_k) or new_k <= 0:
+            return k, lam
+        k, lam = new_k, new_lam
+        if abs(f) < thr:
+            return k, lam
+        nn = _evd_nn(ql, ts, k, h)
+    return k, lam
+
+
+def _evd_h(ql, ts, sc, k, lam, old_h, maxiter=10000, thr=1e-4):
+    h = old_h
+    for _ in range(maxiter + 1):
+        g = gd = 0.0
+        for t, s in zip(ts, sc):
+            l = _fdiv(_flog(k * ql * t), h)
+            nn = (ql - l) * (t - l)
+            a = 2.0 * l - ql - t
+            b = _fdiv(1.0, nn) - k * _fexp(-lam * s)
+            c = _fdiv(-l, h)
+            g += a * b * c
+            gd += 2.0 * b * c * c - _fdiv(a * c, nn) ** 2 - _fdiv(2.0 * a * b * c, h)
+        if abs(g) < thr:
+            return h
+        if gd > 0:
+            h = h * 2.0 if g > 0 else h / 2.0
+        elif g <= 0:
+            h /= 2.0
+        else:
+            h -= _fdiv(g, gd)
+    return h
+
+
+def evd_params(ql, ts, sc, maxiter=10000):
+    """(k, lambda, h, outer iterations run) as statistics/mod.rs:36-123 computes them."""
+    ts = [float(t) for t in ts]
+    sc = [float(s) for s in sc]
+    n = float(len(ts))
+    mean = sum(sc) / n
+    sd = sum((s - mean) ** 2 for s in sc) / n
+    lam0 = 1.0 / sd
+    h = 1.0
+    nn = [ql * t for t in ts]
+    k0 = n / sum(a * _fexp(-lam0 * s) for a, s in zip(nn, sc))
+    ll = n * _flog(lam0 * k0) + sum(_flog(a) - lam0 * s - k0 * a * _fexp(-lam0 * s) for a, s in zip(nn, sc))
+    act_t, act_s = list(ts), list(sc)
+    for it in range(maxiter + 1):
+        k, lam = _evd_k_lambda(ql, act_t, act_s, k0, lam0, h, maxiter)          # outer k0 / lam0: the inner binding is scoped to the body
+        h = _evd_h(ql, act_t, act_s, k, lam, h, maxiter)
+        nn = _evd_nn(ql, ts, k, h)
+        ll_new = n * _flog(lam * k, True) + sum(_flog(a, True) - lam * s - k * a * _fexp(-lam * s) for a, s in zip(nn, sc))
+        if _fdiv(abs(ll_new - ll), ll) < 1e-6:
+            return k, lam, h, it + 1
+        ll = ll_new
+        act_t, act_s = [], []
+        for t, s, a in zip(ts, sc, nn):
+            if n * (1.0 - _fexp(-k * a * _fexp(-lam * s))) >= 1.0:
+                act_t.append(t); act_s.append(s)
+    return k0, lam0, h, maxiter + 1

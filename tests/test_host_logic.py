@@ -206,3 +206,36 @@ def test_c5_digest_fixture_is_the_oracles():
         strings.append((tb[o:o + r.aln_len], tb[o + cap:o + cap + r.aln_len]))
     assert mk.block_digest(summ, strings) == g["digests"][k].tobytes()
     assert (summ[:, 0] == g["scores"][k * 1000:(k + 1) * 1000]).all()
+
+
+def test_evd_fit_keeps_the_references_loop_scoped_rebinding():
+    """statistics/mod.rs:69 re-binds (k, lambda) INSIDE the loop body: every outer iteration restarts from the initial moment
+    estimates, and the fall-through returns them.  The numpy restatement must agree with the scalar hand-run of the Rust
+    logic (tests/pyref.py): on realistic score sets (one outer iteration: the log-likelihood is negative, so the relative
+    test at :104 passes at once), on sets that take several outer iterations, and on sets that fall through the cap."""
+    import pyref
+    from aligner_amd import statistics as st
+    cap = 30
+    seen = set()
+    old = st.MAXITER
+    st.MAXITER = cap                          # same cap for the outer and the inner loops on both sides
+    try:
+        for case in range(16):
+            rng = np.random.default_rng(3 if case >= 4 else 100 + case)
+            if case < 4:                      # Gumbel-ish scores like the shuffled alignments produce
+                n, ql = 60 + 10 * case, 150 + 20 * case
+                lengths = rng.integers(ql - 6, ql + 1, size=n)
+                scores = np.round(rng.gumbel(30.0 + 5 * case, 4.0 + case, size=n))
+            else:                             # tiny-variance scores around zero: positive log-likelihood, several iterations
+                for c in range(case - 3):
+                    n, ql = 40 + 5 * c, 100 + 10 * c
+                    lengths = rng.integers(ql - 6, ql + 1, size=n)
+                    scores = np.round(rng.normal(0.0, [0.05, 0.1, 0.2, 0.3][c % 4], size=n), 3)
+            k, lam, h, iters = pyref.evd_params(ql, lengths.tolist(), scores.tolist(), maxiter=cap)
+            got = st.calculate_distribution_params(ql, lengths, scores)
+            seen.add("one" if iters == 1 else "cap" if iters > cap else "several")
+            for a, b in ((got.k, k), (got.lambda_, lam), (got.h, h)):
+                assert (np.isnan(a) and np.isnan(b)) or a == pytest.approx(b, rel=1e-9, abs=0), (case, iters, got.k, k, got.lambda_, lam, got.h, h)
+    finally:
+        st.MAXITER = old
+    assert seen == {"one", "several", "cap"}, seen

@@ -1,5 +1,5 @@
 """Fault injection for the single-pair route: one strip never runs (ALN_TEST_DROP_STRIP); the run must come back poisoned
-(ERR_DEVICE) within the polls' bounds instead of hanging.  usage: ALN_TEST_DROP_STRIP=<s+1> python tools/test_abort.py"""
+(ERR_DEVICE) within the polls' bounds instead of hanging.  usage: ALN_TEST_DROP_STRIP=<s+1> python tools/abort_check.py"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates aligner_amd/csrc/aln_single_unit.inc: the hand-scheduled gfx950 instruction stream of the steady state of
-the single-pair core-local fill (one wave = one strip, lane = R consecutive rows, anti-diagonal skew; aln_fast.cuh).
+the single-pair core-local fill (one wave = one strip, lane = R consecutive rows, anti-diagonal skew; aln_fast.h).
 
 Why asm, and why ONE statement for the whole steady loop.  A lone wave issues one instruction per ~4-5 cycles whatever
 its kind (VALU, SALU, LDS, s_nop) and nothing hides a memory round trip for it, so the loop is written to the minimum
