@@ -155,8 +155,37 @@ class BatchResult:
         return ((int(r["start_x"]) + 1, int(r["end_x"]) + 1), (int(r["start_y"]) + 1, int(r["end_y"]) + 1))
 
 
-def align_batch(batch, semantics, del_, ext, matrix, device=None, want_traceback=True, **kw):
-    """Blocking batch call: stage, run, fetch.  Returns a BatchResult."""
+def align_batch(batch, semantics, del_, ext, matrix, device=None, want_traceback=True, tb_off=None, outputs=None, blank=98,
+                **kw):
+    """Blocking batch call through aln_align_batch: host buffers in, host buffers out.  The library cuts the batch into
+    chunks and overlaps upload, fill, traceback and download (aln_host.hip).  Returns a BatchResult.
+
+    tb_off: optional caller-chosen offsets of the aligned strings (default: the documented cumulative layout, which the
+    library copies back without a per-pair scatter)."""
+    lib = _ffi.load()
+    outs = outputs if outputs is not None else _ffi.OUT_SCORE | (_ffi.OUT_TRACEBACK if want_traceback else 0)
+    p, keep = runtime.make_params(semantics, del_, ext, matrix, outputs=outs, blank=blank, **kw)
+    n = len(batch)
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    tb = None
+    if want_traceback:
+        if tb_off is None:
+            tb_off, total = batch.tb_layout()
+        else:
+            tb_off = np.ascontiguousarray(tb_off, dtype=np.uint64)
+            cap = 2 * (batch.q_len + batch.t_len + np.uint64(2))
+            total = int((tb_off + cap).max()) if n else 0
+        tb = np.zeros(max(total, 1), dtype=np.uint8)
+    st = lib.aln_align_batch(runtime.context(device), C.byref(p), batch.seqs.ctypes.data, batch.q_off.ctypes.data,
+                             batch.q_len.ctypes.data, batch.t_off.ctypes.data, batch.t_len.ctypes.data, n,
+                             res.ctypes.data, tb.ctypes.data if want_traceback else None,
+                             tb_off.ctypes.data if want_traceback else None)
+    runtime.raise_for_status(st, "aln_align_batch")
+    return BatchResult(batch, res, tb, tb_off if want_traceback else None)
+
+
+def align_batch_staged(batch, semantics, del_, ext, matrix, device=None, want_traceback=True, **kw):
+    """The same through the staged API (aln_batch_create / run / fetch): the whole batch resident in HBM."""
     outs = _ffi.OUT_SCORE | (_ffi.OUT_TRACEBACK if want_traceback else 0)
     sb = StagedBatch(batch, semantics, del_, ext, matrix, device=device, outputs=outs, **kw)
     try:

@@ -19,7 +19,10 @@
 //               3 Beginning (aln_tag_to_dir maps it to the reference's Direction discriminant).
 //             serial-order fallback (layout 1): plain row-major, row stride (N+4)/4 bytes, 4 cells per byte.
 //   results : aln_pair_result[n]
-//   tb      : aligned code strings, pair i at tb_off: query string then (M+N+2 bytes later) target string
+//   tb      : aligned code strings, pair i at tb_off: query string then (M+N+2 bytes later) target string -- cumulative
+//             2 * (N + M + 2) per pair in the caller's pair order, i.e. exactly the layout aln_align_batch documents for tb_buf,
+//             so a chunk's strings go back to the caller with ONE copy when the caller uses that layout
+//   tags    : the walk's 2-bit tag string (one byte per step), pair i at tag_off, N + M + 2 bytes
 //   scratch : per wave: strip boundary row (score type, N+66 entries), advice bytes, bottom-row zero bytes
 #pragma once
 #include <stdint.h>
@@ -39,10 +42,14 @@ struct PairDesc {
     uint32_t N, M;           // query / target length
     uint64_t dir_off;        // into dirs, multiple of 256
     uint64_t tb_off;         // into tb
+    uint64_t tag_off;        // into tags
     uint64_t h_off;          // element offset into the optional H matrix buffer
     int32_t status;          // pre-validation status; != 0 -> kernels skip the pair
     uint32_t layout;         // written by the fill kernel
 };
+// pre-validation status "nothing to align, and the reference returns Ok": PWMAligner with an empty sequence (pwm/mod.rs:52-108:
+// the loops do not run, argmax is (0, 0), the traceback stops at once, f = 0).  The kernels skip the pair and report ALN_OK.
+#define ALN_PRE_EMPTY_OK (-1)
 
 struct FillArgs {
     const uint8_t *seqs;
@@ -109,6 +116,7 @@ struct TraceArgs {
     const uint8_t *dirs;
     aln_pair_result *results;
     uint8_t *tb;
+    uint8_t *tags;
     int32_t semantics;
     uint8_t blank;
     uint8_t pwm;
@@ -130,6 +138,7 @@ struct TraceSingleArgs {
     const uint8_t *dirs;
     aln_pair_result *results;
     uint8_t *tb;
+    uint8_t *tags;
     int32_t semantics;
     uint32_t R, ns;
     uint4 *map;               // ns x (N + 1) entries {exit cx, exit cy, steps, stopped}

@@ -1,27 +1,51 @@
 // aln_host.hip -- host side of the C ABI declared in include/aligner_hip.h.
 //
-// Batch packing (validation, LPT ordering, direction-region layout), HBM staging, kernel launches on a HIP
-// stream, result fetch.  One context per process per GPU; multi-GPU runs are one process per GPU (the Python
-// driver shards pairs across ranks and gathers the 48-byte summaries with RCCL through torch.distributed).
-// There is NO CPU implementation of the DP here: if the device or the kernels are unavailable every entry point
-// fails with ALN_ERR_DEVICE.
+// The reference's callers own host buffers (Vec<T> per sequence, statistics/mod.rs:255-286; simple/mod.rs:35-40) and get
+// owned results back, so the entry points take HOST pointers and everything between them and the kernels lives here:
+//
+//   plan      per chunk of pairs: validation of the lengths, routing (batch kernel / single-pair kernel), LPT order of the
+//             device work queue, layout of the direction, string and tag regions            (chunk_plan)
+//   pool      every context owns a few SLOTS: device buffers (grow-only), a stream, pinned staging for the small tables --
+//             nothing is hipMalloc'ed per call once the pool is warm                         (Slot, slot_ensure)
+//   pipeline  aln_align_batch cuts the batch into chunks of ~1e10 cells in the CALLER's pair order, so that a chunk's
+//             residues, summaries and aligned strings are contiguous spans of the caller's buffers: one H2D and two D2H
+//             copies per chunk, straight from / into the caller's memory (no bounce, no per-pair memcpy; the runtime moves
+//             pageable memory at the link rate, profiles/r02_host_link.txt).  Chunk i+1 is staged and chunk i-1 is fetched
+//             (by a second host thread) while chunk i fills; chunks run on different slots = different streams, so the
+//             tail of one fill, the traceback behind it and the head of the next fill overlap on the device, and the
+//             directions of a chunk only live until its traceback is done (4 x ~2.5 GB instead of 35 GB for C5).
+//   staged    aln_batch_* keeps ONE chunk = the whole batch resident in a private slot (inputs in HBM before the timed
+//             region: what bench.py's headline measures) -- same plan, same launches.
+//
+// One context per process per GPU; multi-GPU runs are one process per GPU (the Python driver shards pairs across ranks and
+// gathers the 48-byte summaries with RCCL through torch.distributed).  There is NO CPU implementation of the DP here: if the
+// device or the kernels are unavailable every entry point fails with ALN_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "aln_device.h"
 
 #define ALN_TIMING_SLOTS 256u
+// HIP multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES): with more slots than that two chunks share a
+// queue and wait for each other (measured: 6 slots 67 ms, 4 slots 57 ms for the C5 batch)
+#define ALN_POOL_SLOTS 4
 
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
+extern "C" void aln_launch_validate(const uint8_t *seqs, PairDesc *descs, uint32_t n_pairs, uint32_t rows, uint32_t cols, int pwm,
+                                    hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_overlap(const TraceArgs *a, uint32_t waves, hipStream_t s);
 extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
@@ -33,82 +57,6 @@ extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, ui
                                   uint64_t cells, hipStream_t s);
 
 static thread_local std::string g_err;
-
-struct aln_ctx {
-    int device = 0;
-    int cus = 0;
-    size_t hbm = 0;
-    char name[128] = {0};
-    hipStream_t stream = nullptr;
-    std::mutex mu;
-};
-
-// bytes of the single-pair kernel's advice array and of its bottom-row record (one direction dword per block of the last
-// strip, at most (N + 63) / 2 + 4 blocks at R = 8), equal sizes, 256-aligned
-static inline uint64_t single_advice_bytes(uint64_t N)
-{
-    const uint64_t a = N + 128, z = 4 * ((N + 63) / 2 + 8);
-    return ((a > z ? a : z) + 255) & ~255ull;
-}
-
-struct aln_batch {
-    aln_ctx *ctx = nullptr;
-    aln_params params{};
-    size_t n = 0;
-    bool is_int = true;
-    bool pwm = false;         // ALN_PWM_LOCAL: kernels run as CORE_LOCAL with position-specific scoring
-    uint32_t *d_pwm_words = nullptr;
-    bool store_dirs = true;   // false: score-only batch (outputs has neither TRACEBACK nor DIRECTIONS)
-    bool fast = false;        // integer kernels with the LDS query profile + packed max3 keys
-    uint32_t prof_stride = 0;
-    uint64_t cells = 0;
-    uint64_t dir_bytes = 0;
-    uint64_t tb_bytes = 0;
-    uint32_t max_len = 0;
-    uint32_t grid = 0;
-    uint64_t scratch_stride = 0;
-    uint32_t zrow_bytes = 0;
-    uint32_t lds_bytes = 0;
-    std::vector<PairDesc> descs;
-    // device
-    uint8_t *d_seqs = nullptr;
-    PairDesc *d_descs = nullptr;
-    uint32_t *d_order = nullptr;
-    uint32_t *d_counter = nullptr;
-    // overlapped traceback (aln_batch_run): second stream, fork/join events, per-pair "walked in run #epoch" marks
-    bool overlap = false;
-    uint32_t tb_waves = 0, epoch = 0;
-    size_t counter_bytes = 256;
-    uint32_t *d_walked = nullptr;
-    hipStream_t tb_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    uint8_t *d_dirs = nullptr;
-    aln_pair_result *d_results = nullptr;
-    uint8_t *d_tb = nullptr;
-    uint8_t *d_scratch = nullptr;
-    void *d_matrix = nullptr;
-    void *d_hmat = nullptr;
-    uint64_t hmat_elems = 0;
-    // pairs routed to the single-pair (one wave per strip) kernel, processed one after another
-    std::vector<uint32_t> single_pairs;
-    std::vector<uint32_t> single_r;
-    size_t n_small = 0;
-    uint64_t max_cells = 0;
-    uint32_t *d_granules = nullptr;
-    uint64_t granule_bytes = 0;
-    uint8_t *d_advice1 = nullptr;
-    int32_t *d_cand = nullptr;
-    uint32_t *d_ctrl = nullptr;
-    uint32_t single_max_n = 0;
-    uint4 *d_tbmap = nullptr;   // parallel traceback of large pairs: exit maps + per-strip segments
-    uint64_t tbmap_entries = 0;
-    hipStream_t last_stream = nullptr;
-    // timing ring: one event triple per run (fill start, fill end, traceback end), recorded on the launch stream
-    bool timing = false;
-    std::vector<hipEvent_t> ev;
-    uint32_t ev_runs = 0;
-    uint32_t fill_launches = 0;
-};
 
 static int fail(hipError_t e, const char *what)
 {
@@ -122,6 +70,126 @@ static int fail(hipError_t e, const char *what)
         hipError_t e_ = (call);                              \
         if (e_ != hipSuccess) return fail(e_, #call);        \
     } while (0)
+
+// ---------------------------------------------------------------- grow-only buffers
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+static int dev_ensure(DevBuf &b, size_t bytes, bool slack)
+{
+    bytes = std::max<size_t>(bytes, 256);
+    if (b.cap >= bytes) return ALN_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = slack ? bytes + bytes / 8 : bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess && want != bytes) { want = bytes; e = hipMalloc(&b.p, want); }
+    if (e != hipSuccess) { b.p = nullptr; return fail(e, "hipMalloc"); }
+    b.cap = want;
+    return ALN_OK;
+}
+static void dev_free(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+static int pin_ensure(PinBuf &b, size_t bytes)
+{
+    bytes = std::max<size_t>(bytes, 4096);
+    if (b.cap >= bytes) return ALN_OK;
+    if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { b.p = nullptr; return fail(e, "hipHostMalloc"); }
+    b.cap = want;
+    return ALN_OK;
+}
+static void pin_free(PinBuf &b)
+{
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+// ---------------------------------------------------------------- a slot: everything one chunk needs on the device
+struct Slot {
+    bool pooled = true;       // pool slots keep some slack when they grow; a staged batch's private slot is sized exactly
+    DevBuf seqs, descs, order, counter, walked, dirs, results, tb, tags, scratch, matrix, pwm_words, hmat;
+    DevBuf granules, advice1, cand, ctrl, tbmap, unpack;
+    PinBuf h_meta;            // descs + order + matrix + pwm words (small, truly asynchronous H2D)
+    PinBuf h_in, h_out;       // fallback staging: sequences gathered from scattered offsets / strings for a foreign tb layout
+    hipStream_t stream = nullptr;
+    hipStream_t tb_stream = nullptr;                 // in-kernel overlapped traceback (staged batches)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr, ev_fill = nullptr;
+    uint32_t epoch = 0;
+    bool walked_clean = false;
+};
+
+struct aln_ctx {
+    int device = 0;
+    int cus = 0;
+    size_t hbm = 0;
+    char name[128] = {0};
+    std::mutex mu;                                   // guards the pool
+    std::condition_variable cv;
+    Slot *slots[ALN_POOL_SLOTS] = {nullptr};
+    bool busy[ALN_POOL_SLOTS] = {false};
+};
+
+static int slot_init(Slot &s)
+{
+    if (!s.stream) HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (!s.ev_done) HIPCHK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    if (!s.ev_fill) HIPCHK(hipEventCreateWithFlags(&s.ev_fill, hipEventDisableTiming));
+    return ALN_OK;
+}
+static void slot_destroy(Slot *s)
+{
+    if (!s) return;
+    DevBuf *d[] = {&s->seqs, &s->descs, &s->order, &s->counter, &s->walked, &s->dirs, &s->results, &s->tb, &s->tags, &s->scratch,
+                   &s->matrix, &s->pwm_words, &s->hmat, &s->granules, &s->advice1, &s->cand, &s->ctrl, &s->tbmap, &s->unpack};
+    for (DevBuf *b : d) dev_free(*b);
+    pin_free(s->h_meta); pin_free(s->h_in); pin_free(s->h_out);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+    if (s->ev_fill) (void)hipEventDestroy(s->ev_fill);
+    if (s->tb_stream) (void)hipStreamDestroy(s->tb_stream);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+// takes between 1 and `want` free pool slots (blocks while none is free); concurrent callers share the pool
+static int pool_lease(aln_ctx *ctx, int want, Slot **out)
+{
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    int got = 0;
+    for (;;) {
+        for (int i = 0; i < ALN_POOL_SLOTS && got < want; ++i)
+            if (!ctx->busy[i]) {
+                if (!ctx->slots[i]) ctx->slots[i] = new Slot();
+                ctx->busy[i] = true;
+                out[got++] = ctx->slots[i];
+            }
+        if (got) return got;
+        ctx->cv.wait(lk);
+    }
+}
+static void pool_release(aln_ctx *ctx, Slot **slots, int n)
+{
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (int k = 0; k < n; ++k)
+            for (int i = 0; i < ALN_POOL_SLOTS; ++i)
+                if (ctx->slots[i] == slots[k]) ctx->busy[i] = false;
+    }
+    ctx->cv.notify_all();
+}
 
 extern "C" const char *aln_last_error(void) { return g_err.c_str(); }
 extern "C" int aln_abi_version(void) { return ALN_ABI_VERSION; }
@@ -148,11 +216,6 @@ extern "C" aln_ctx *aln_create(int device_id, int *status)
             c->cus = prop.multiProcessorCount;
             c->hbm = prop.totalGlobalMem;
             snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
-            if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-                st = fail(e, "hipStreamCreate");
-                delete c;
-                c = nullptr;
-            }
         }
     }
     if (status) *status = st;
@@ -163,7 +226,7 @@ extern "C" void aln_destroy(aln_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (Slot *s : ctx->slots) slot_destroy(s);
     delete ctx;
 }
 
@@ -176,121 +239,155 @@ extern "C" int aln_device_info(aln_ctx *ctx, int *cus, size_t *hbm, char *name, 
     return ALN_OK;
 }
 
+// ---------------------------------------------------------------- per call: arguments of perform_alignment, analysed once
+struct Call {
+    aln_params p{};
+    bool pwm = false, core = false;
+    uint32_t rows = 0, cols = 0;
+    std::vector<double> md;           // the matrix, compact row-major
+    bool all_int = false;
+    double maxabs = 0, smin = 0, smax = 0;
+    uint32_t outs = 0;
+    bool store_dirs = true, want_tb = true, want_h = false;
+    bool is_int = true, fast = false; // decided from the whole batch (the longest pair), the same for every chunk
+    int semantics = 0;                // what the kernels run (PWM runs as CORE_LOCAL with position-specific scoring)
+};
+
 static bool integral(double v) { return std::isfinite(v) && v == std::floor(v) && std::fabs(v) < 1e9; }
 
-static void batch_free(aln_batch *b)
+// bytes of the single-pair kernel's advice array and of its bottom-row record (one direction dword per block of the last
+// strip, at most (N + 63) / 2 + 4 blocks at R = 8), equal sizes, 256-aligned
+static inline uint64_t single_advice_bytes(uint64_t N)
 {
-    if (!b) return;
-    (void)hipSetDevice(b->ctx->device);
-    void *ptrs[] = {b->d_seqs, b->d_descs, b->d_order, b->d_counter, b->d_dirs, b->d_results, b->d_tb, b->d_scratch,
-                    b->d_matrix, b->d_hmat, b->d_granules, b->d_advice1, b->d_cand, b->d_ctrl, b->d_tbmap, b->d_pwm_words};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
-    if (b->d_walked) (void)hipFree(b->d_walked);
-    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
-    if (b->tb_stream) (void)hipStreamDestroy(b->tb_stream);
-    delete b;
+    const uint64_t a = N + 128, z = 4 * ((N + 63) / 2 + 8);
+    return ((a > z ? a : z) + 255) & ~255ull;
 }
 
-extern "C" void aln_batch_destroy(aln_batch *b) { batch_free(b); }
-
-static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, const uint64_t *q_off,
-                       const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n, bool want_h,
-                       aln_batch **out)
+static int call_init(Call &c, const aln_params *p, const uint64_t *q_len, const uint64_t *t_len, size_t n, bool want_h)
 {
-    *out = nullptr;
-    if (!ctx || !p || (n && (!seqs || !q_off || !q_len || !t_off || !t_len))) { g_err = "null argument"; return ALN_ERR_INVALID_ARGUMENT; }
+    if (!p) { g_err = "null argument"; return ALN_ERR_INVALID_ARGUMENT; }
     if (p->semantics < ALN_CORE_GLOBAL || p->semantics > ALN_PWM_LOCAL) { g_err = "bad semantics"; return ALN_ERR_INVALID_ARGUMENT; }
-    const bool pwm = p->semantics == ALN_PWM_LOCAL;
-    const bool core = p->semantics == ALN_CORE_GLOBAL || p->semantics == ALN_CORE_LOCAL || pwm;
+    c.p = *p;
+    c.pwm = p->semantics == ALN_PWM_LOCAL;
+    c.core = p->semantics == ALN_CORE_GLOBAL || p->semantics == ALN_CORE_LOCAL || c.pwm;
+    c.semantics = c.pwm ? ALN_CORE_LOCAL : p->semantics;       // same recurrence and tie rules; only the score lookup differs
     // simple/mod.rs:49-51 / :175-177
-    if (core && p->heuristics_present) return ALN_ERR_UNNECESSARY_ARGUMENT;
+    if (c.core && p->heuristics_present) return ALN_ERR_UNNECESSARY_ARGUMENT;
     if (!p->matrix || p->rows == 0 || p->cols == 0) { g_err = "matrix missing"; return ALN_ERR_INVALID_ARGUMENT; }
-    if (pwm && p->rows != 4) return ALN_ERR_MATRIX_SHAPE;                      // pwm/mod.rs:40-42
+    if (c.pwm && p->rows != 4) return ALN_ERR_MATRIX_SHAPE;                    // pwm/mod.rs:40-42
     // the matrix lives in LDS: 32 KiB next to the query profiles; a position-weight matrix (no profiles in LDS) may be
     // 4 x 2000 wide (62.5 KiB as f64)
-    if ((uint64_t)p->rows * p->cols > (pwm ? 8000u : 4096u)) {
-        g_err = pwm ? "position-weight matrix larger than 8000 entries (4 x 2000)" : "substitution matrix larger than 4096 entries";
+    if ((uint64_t)p->rows * p->cols > (c.pwm ? 8000u : 4096u)) {
+        g_err = c.pwm ? "position-weight matrix larger than 8000 entries (4 x 2000)" : "substitution matrix larger than 4096 entries";
         return ALN_ERR_UNSUPPORTED;
     }
     if (n > 0xFFFFFFF0ull) { g_err = "too many pairs"; return ALN_ERR_UNSUPPORTED; }
-    HIPCHK(hipSetDevice(ctx->device));
-
-    aln_batch *b = new aln_batch();
-    b->ctx = ctx;
-    b->params = *p;
-    b->params.matrix = nullptr;
-    b->n = n;
-    b->pwm = pwm;
-    if (pwm) b->params.semantics = ALN_CORE_LOCAL;   // same recurrence and tie rules; only the score lookup differs
-
-    // ---- compact the matrix, pick the arithmetic
-    const uint32_t rows = p->rows, cols = p->cols;
-    const int64_t rs = p->row_stride ? p->row_stride : (int64_t)cols;
-    std::vector<double> md((size_t)rows * cols);
-    double maxabs = std::max(std::fabs(p->del), std::fabs(p->ext));
-    bool all_int = integral(p->del) && (core ? integral(p->ext) : true);
-    for (uint32_t r = 0; r < rows; ++r)
-        for (uint32_t c = 0; c < cols; ++c) {
-            double v = p->matrix[(int64_t)r * rs + c];
-            md[(size_t)r * cols + c] = v;
-            all_int = all_int && integral(v);
-            maxabs = std::max(maxabs, std::fabs(v));
+    c.rows = p->rows; c.cols = p->cols;
+    const int64_t rs = p->row_stride ? p->row_stride : (int64_t)c.cols;
+    c.md.resize((size_t)c.rows * c.cols);
+    c.maxabs = std::max(std::fabs(p->del), std::fabs(p->ext));
+    c.all_int = integral(p->del) && (c.core ? integral(p->ext) : true);
+    c.smin = 0; c.smax = 0;
+    for (uint32_t r = 0; r < c.rows; ++r)
+        for (uint32_t k = 0; k < c.cols; ++k) {
+            const double v = p->matrix[(int64_t)r * rs + k];
+            c.md[(size_t)r * c.cols + k] = v;
+            c.all_int = c.all_int && integral(v);
+            c.maxabs = std::max(c.maxabs, std::fabs(v));
+            c.smin = std::min(c.smin, v); c.smax = std::max(c.smax, v);
         }
-    if (!core && !all_int) { g_err = "legacy semantics are i32: del and matrix must be integral"; batch_free(b); return ALN_ERR_INVALID_ARGUMENT; }
-    if (!core && p->force_f64) { g_err = "legacy semantics have no f64 form"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
-
-    // ---- per-pair validation
-    b->descs.resize(n);
-    uint64_t cells = 0;
-    uint32_t max_len = 1;
+    if (!c.core && !c.all_int) { g_err = "legacy semantics are i32: del and matrix must be integral"; return ALN_ERR_INVALID_ARGUMENT; }
+    if (!c.core && p->force_f64) { g_err = "legacy semantics have no f64 form"; return ALN_ERR_UNSUPPORTED; }
+    c.outs = p->outputs ? p->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
+    c.store_dirs = (c.outs & (ALN_OUT_TRACEBACK | ALN_OUT_DIRECTIONS)) != 0;
+    c.want_tb = (c.outs & ALN_OUT_TRACEBACK) != 0;
+    c.want_h = want_h;
     uint64_t max_span = 0;
     for (size_t i = 0; i < n; ++i) {
-        PairDesc &d = b->descs[i];
-        memset(&d, 0, sizeof d);
-        d.q_off = q_off[i];
-        d.t_off = t_off[i];
-        if (q_len[i] > 0x7FFFFFF0ull || t_len[i] > 0x7FFFFFF0ull) { g_err = "sequence too long"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
-        d.N = pwm ? cols : (uint32_t)q_len[i];                                 // PWM: the columns are the PWM positions
-        d.M = (uint32_t)t_len[i];
-        d.status = ALN_OK;
-        if (d.N == 0 || d.M == 0) d.status = ALN_ERR_EMPTY_SEQUENCE;          // reference panics (PWM: treated alike)
-        else {
-            const uint8_t *q = seqs + d.q_off, *t = seqs + d.t_off;
-            if (!pwm) for (uint32_t k = 0; k < d.N && d.status == ALN_OK; ++k) if (q[k] >= cols) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
-            for (uint32_t k = 0; k < d.M && d.status == ALN_OK; ++k) if (t[k] >= rows) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
-        }
-        if (d.status != ALN_OK) continue;
-        cells += (uint64_t)d.N * d.M;
-        max_len = std::max(max_len, std::max(d.N, d.M));
-        max_span = std::max(max_span, (uint64_t)d.N + d.M + 2);
+        if (q_len[i] > 0x7FFFFFF0ull || t_len[i] > 0x7FFFFFF0ull) { g_err = "sequence too long"; return ALN_ERR_UNSUPPORTED; }
+        const uint64_t N = c.pwm ? c.cols : q_len[i], M = t_len[i];
+        if (N && M) max_span = std::max(max_span, N + M + 2);
     }
-    b->cells = cells;
-    b->max_len = max_len;
     // integer kernels are exact iff every value is integral and |H| cannot leave i32
-    b->is_int = all_int && !p->force_f64 && maxabs * (double)max_span < 1073741824.0;
-    if (!core && !b->is_int) { g_err = "legacy scores overflow i32 for these lengths"; batch_free(b); return ALN_ERR_UNSUPPORTED; }
-    // fast integer kernels: keys are 4*H + tag in i32 and the profile holds 4*s - 1 as int8
-    double smin = 0, smax = 0;
-    for (double v : md) { smin = std::min(smin, v); smax = std::max(smax, v); }
-    b->fast = b->is_int && !want_h && !p->force_serial && !p->force_generic && (pwm || cols <= 64) && smin >= -31.0 && smax <= 32.0 &&
-              maxabs * (double)max_span < 268435456.0;
+    c.is_int = c.all_int && !p->force_f64 && c.maxabs * (double)max_span < 1073741824.0;
+    if (!c.core && !c.is_int) { g_err = "legacy scores overflow i32 for these lengths"; return ALN_ERR_UNSUPPORTED; }
+    // fast integer kernels: keys are 4*H + tag in i32, the profile holds 4*s - 2 as int8, and S + four waves' profiles
+    // (cols x 512 B each) have to fit the 64 KiB of LDS a workgroup gets without an opt-in
+    const uint64_t fast_lds = (((uint64_t)c.rows * c.cols * 4 + 15) & ~15ull) + (c.pwm ? 0ull : 4ull * c.cols * 64u * ALN_FULL_R);
+    c.fast = c.is_int && !want_h && !p->force_serial && !p->force_generic && fast_lds <= 65536 && c.smin >= -31.0 && c.smax <= 32.0 &&
+             c.maxabs * (double)max_span < 268435456.0;
+    return ALN_OK;
+}
 
-    {
-        const uint32_t outs = p->outputs ? p->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
-        b->store_dirs = (outs & (ALN_OUT_TRACEBACK | ALN_OUT_DIRECTIONS)) != 0;
-    }
-    // ---- routing + HBM layout.  A pair goes to the single-pair kernel (one wave per strip, strips pipelined across
-    // CUs) when it is large, or when the batch is too small to fill the chip with one wave per pair.
-    uint64_t dir_total = 0, tb_total = 0, hm_total = 0;
+// ---------------------------------------------------------------- per chunk: descriptors, routing, layout
+struct Chunk {
+    size_t first = 0, n = 0;          // pairs [first, first + n) of the call
+    std::vector<PairDesc> descs;
+    std::vector<uint32_t> order;      // LPT order of the device work queue (pairs of the batch kernel)
+    std::vector<uint32_t> single_pairs, single_r;   // pairs routed to the single-pair (one wave per strip) kernel
+    size_t n_small = 0;
+    uint64_t cells = 0, max_cells = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, hmat_elems = 0;
+    uint32_t max_len = 1, grid = 1, zrow_bytes = 0, lds_bytes = 0, prof_stride = 0, tb_waves = 0, single_max_n = 0;
+    uint64_t scratch_stride = 0, granule_bytes = 0, tbmap_entries = 0;
+    size_t counter_bytes = 256;
+    bool overlap = false;             // walk waves beside the fill (in-kernel overlapped traceback)
+    // sequences: either one contiguous span of the caller's buffer, or gathered pair by pair into pinned staging
+    bool seq_direct = true;
+    uint64_t seq_lo = 0, seq_span = 0;
+};
+
+static int chunk_plan(const aln_ctx *ctx, const Call &c, const uint64_t *q_off, const uint64_t *q_len, const uint64_t *t_off,
+                      const uint64_t *t_len, size_t first, size_t n, bool allow_overlap, Chunk &k)
+{
+    k.first = first; k.n = n;
+    k.descs.assign(n, PairDesc{});
+    const bool pwm = c.pwm;
+    const uint32_t rows = c.rows, cols = c.cols;
     const char *env_r = getenv("ALN_SINGLE_R");
     const char *env_off = getenv("ALN_NO_SINGLE");
+    uint64_t seq_lo = ~0ull, seq_hi = 0, seq_sum = 0;
     for (size_t i = 0; i < n; ++i) {
-        PairDesc &d = b->descs[i];
+        const size_t g = first + i;
+        PairDesc &d = k.descs[i];
+        d.N = pwm ? cols : (uint32_t)q_len[g];                                 // PWM: the columns are the PWM positions
+        d.M = (uint32_t)t_len[g];
+        d.status = ALN_OK;
+        if (d.N == 0 || d.M == 0) d.status = (pwm && d.N != 0) ? ALN_PRE_EMPTY_OK : ALN_ERR_EMPTY_SEQUENCE;   // the reference panics
+        if (!pwm && q_len[g]) { seq_lo = std::min(seq_lo, q_off[g]); seq_hi = std::max(seq_hi, q_off[g] + q_len[g]); seq_sum += q_len[g]; }
+        if (t_len[g]) { seq_lo = std::min(seq_lo, t_off[g]); seq_hi = std::max(seq_hi, t_off[g] + t_len[g]); seq_sum += t_len[g]; }
+    }
+    if (seq_lo == ~0ull) { seq_lo = 0; seq_hi = 0; }
+    // the chunk's residues are one span of the caller's buffer unless the offsets are scattered far beyond what the chunk uses
+    k.seq_direct = (seq_hi - seq_lo) <= 2 * seq_sum + 65536;
+    k.seq_lo = seq_lo;
+    k.seq_span = k.seq_direct ? seq_hi - seq_lo : seq_sum;
+    uint64_t gpos = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t g = first + i;
+        PairDesc &d = k.descs[i];
+        if (k.seq_direct) { d.q_off = pwm ? 0 : q_off[g] - (q_len[g] ? seq_lo : q_off[g]); d.t_off = t_len[g] ? t_off[g] - seq_lo : 0; }
+        else { d.q_off = gpos; gpos += pwm ? 0 : q_len[g]; d.t_off = gpos; gpos += t_len[g]; }
+    }
+
+    // ---- routing + HBM layout.  A pair goes to the single-pair kernel (one wave per strip, strips pipelined across
+    // CUs) when it is large, or when the chunk is too small to fill the chip with one wave per pair.
+    uint64_t dir_total = 0, tb_total = 0, tag_total = 0, hm_total = 0, cells = 0;
+    uint32_t max_len = 1;
+    for (size_t i = 0; i < n; ++i) {
+        PairDesc &d = k.descs[i];
+        // strings: cumulative 2 * cap per pair (PWM: 5 * cap, 4-aligned) -- the layout aln_align_batch documents for tb_buf
+        const uint64_t cap = (uint64_t)d.N + d.M + 2;
+        if (c.store_dirs) {
+            d.tb_off = tb_total;
+            tb_total += pwm ? ((5ull * cap + 3) & ~3ull) : 2ull * cap;
+            d.tag_off = tag_total;
+            tag_total += (cap + 3) & ~3ull;
+        }
         if (d.status != ALN_OK) continue;
         const uint64_t pc = (uint64_t)d.N * d.M;
-        bool single = b->fast && !pwm && !env_off && d.N >= 64 && d.M >= 128 && (pc >= (1ull << 24) || (n <= 16 && pc >= (1ull << 18)));
+        cells += pc;
+        max_len = std::max(max_len, std::max(d.N, d.M));
+        bool single = c.fast && !pwm && !env_off && d.N >= 64 && d.M >= 128 && (pc >= (1ull << 24) || (n <= 16 && pc >= (1ull << 18)));
         uint64_t dbytes = aln_dir_bytes(d.N, d.M);
         if (single) {
             uint32_t R = env_r ? (uint32_t)atoi(env_r) : (d.M > 4096 ? 2u : 1u);
@@ -299,146 +396,560 @@ static int batch_build(aln_ctx *ctx, const aln_params *p, const uint8_t *seqs, c
             if ((d.M + 64 * R - 1) / (64 * R) > 4096) single = false;
             if ((uint64_t)rows * cols * 4 + (uint64_t)cols * 64 * R + 2ull * (d.N + 192) + 1024 > 65536) single = false;   // LDS budget
             if (single) {
-                const uint32_t ns = (d.M + 64 * R - 1) / (64 * R), spb = 16 / R;
+                const uint32_t ns = (d.M + 64 * R - 1) / (64 * R);
                 dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * aln_uniform_strip_bytes(d.N, R));
-                (void)spb;
-                b->single_pairs.push_back((uint32_t)i);
-                b->single_r.push_back(R);
+                k.single_pairs.push_back((uint32_t)i);
+                k.single_r.push_back(R);
                 const uint64_t gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
-                b->granule_bytes = std::max<uint64_t>(b->granule_bytes, std::max<uint64_t>((uint64_t)ns * gstride * 4, 4ull * (d.M + 2)));
-                b->single_max_n = std::max(b->single_max_n, std::max(d.N, ns));
-                b->tbmap_entries = std::max<uint64_t>(b->tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
+                k.granule_bytes = std::max<uint64_t>(k.granule_bytes, std::max<uint64_t>((uint64_t)ns * gstride * 4, 4ull * (d.M + 2)));
+                k.single_max_n = std::max(k.single_max_n, std::max(d.N, ns));
+                k.tbmap_entries = std::max<uint64_t>(k.tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
             }
         }
         d.dir_off = dir_total;
-        if (b->store_dirs) {
-            dir_total += dbytes;
-            d.tb_off = tb_total;
-            // aligned query, aligned target, traceback tag scratch (PWM: u32 column numbers, residues, tags)
-            tb_total += ((pwm ? 6ull : 3ull) * ((uint64_t)d.N + d.M + 2) + 3) & ~3ull;
-        }   // aligned query, aligned target, traceback tag scratch
-        if (want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
+        if (c.store_dirs) dir_total += dbytes;
+        if (c.want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
     }
-    b->dir_bytes = dir_total;
-    b->tb_bytes = tb_total;
-    b->hmat_elems = hm_total;
+    k.cells = cells; k.max_len = max_len;
+    k.dir_bytes = dir_total; k.tb_bytes = tb_total; k.tag_bytes = tag_total; k.hmat_elems = hm_total;
 
     // ---- LPT order: largest pairs first into the device work queue
-    std::vector<uint32_t> order;
-    order.reserve(n);
+    k.order.clear();
+    k.order.reserve(n);
     {
         std::vector<char> is_single(n, 0);
-        for (uint32_t i : b->single_pairs) is_single[i] = 1;
-        for (size_t i = 0; i < n; ++i) if (!is_single[i]) order.push_back((uint32_t)i);
+        for (uint32_t i : k.single_pairs) is_single[i] = 1;
+        for (size_t i = 0; i < n; ++i) if (!is_single[i]) k.order.push_back((uint32_t)i);
     }
-    b->n_small = order.size();
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
-        return (uint64_t)b->descs[a].N * b->descs[a].M > (uint64_t)b->descs[c].N * b->descs[c].M;
-    });
-
-    b->max_cells = order.empty() ? 0 : (uint64_t)b->descs[order[0]].N * b->descs[order[0]].M;
+    k.n_small = k.order.size();
+    {
+        // sort keys packed in one u64: cells descending, then index ascending (a stable order without a stable_sort)
+        std::vector<uint64_t> key(k.n_small);
+        bool packable = n < (1u << 24);
+        for (size_t j = 0; j < k.n_small && packable; ++j) {
+            const PairDesc &d = k.descs[k.order[j]];
+            const uint64_t pc = d.status == ALN_OK ? (uint64_t)d.N * d.M : 0;
+            if (pc >= (1ull << 40)) { packable = false; break; }
+            key[j] = ((~pc & ((1ull << 40) - 1)) << 24) | k.order[j];
+        }
+        if (packable) {
+            std::sort(key.begin(), key.end());
+            for (size_t j = 0; j < k.n_small; ++j) k.order[j] = (uint32_t)(key[j] & 0xffffffu);
+        } else {
+            std::stable_sort(k.order.begin(), k.order.end(), [&](uint32_t a, uint32_t b) {
+                return (uint64_t)k.descs[a].N * k.descs[a].M > (uint64_t)k.descs[b].N * k.descs[b].M;
+            });
+        }
+    }
+    k.max_cells = k.order.empty() ? 0 : (uint64_t)k.descs[k.order[0]].N * k.descs[k.order[0]].M;
 
     // ---- grid: persistent waves, 4 per workgroup
-    const uint32_t wg_needed = (uint32_t)((b->n_small + 3) / 4);
-    b->grid = std::max(1u, std::min(wg_needed, (uint32_t)ctx->cus * 4u));
-    // Overlapped traceback (aln_batch_run): the walk kernel runs beside the fill.  The fast fill kernel is built for 160 VGPRs,
+    const uint32_t wg_needed = (uint32_t)((k.n_small + 3) / 4);
+    k.grid = std::max(1u, std::min(wg_needed, (uint32_t)ctx->cus * 4u));
+    // Overlapped traceback: the walk kernel runs beside the fill.  The fast fill kernel is built for 160 VGPRs,
     // three workgroups per CU, so that every SIMD keeps 32 registers free: exactly one wave of the walk kernel (32 VGPRs, no
     // LDS).  ALN_TB_OVERLAP: unset = one walk wave per SIMD beside a full fill grid; 0 = off; n > 0 = the earlier scheme (the
     // fill grid stops n workgroups short of residency and the walk waves crowd onto those CUs, 20 per slot).
     {
-        const uint32_t outs = p->outputs ? p->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
         const uint32_t resident = (uint32_t)ctx->cus * 3u;
         const char *e = getenv("ALN_TB_OVERLAP");
         const uint32_t reserve = e ? (uint32_t)atoi(e) : 0u;
         const bool off = e && reserve == 0;
-        b->overlap = !off && b->fast && b->is_int && (outs & ALN_OUT_TRACEBACK) && reserve < resident &&
-                     b->n_small >= 4096 && wg_needed >= resident;
-        if (b->overlap) {
-            b->grid = resident - reserve;
-            b->tb_waves = reserve ? reserve * 20u : (uint32_t)ctx->cus * 4u;
-            b->counter_bytes = 256 + 4ull * b->n_small;
+        k.overlap = allow_overlap && !off && c.fast && c.is_int && c.want_tb && c.store_dirs && reserve < resident &&
+                    k.n_small >= 4096 && wg_needed >= resident;
+        k.counter_bytes = 256;
+        if (k.overlap) {
+            k.grid = resident - reserve;
+            k.tb_waves = reserve ? reserve * 20u : (uint32_t)ctx->cus * 4u;
+            k.counter_bytes = 256 + 4ull * k.n_small;
         }
     }
-    const uint64_t sc_size = b->is_int ? 4 : 8;
+    const uint64_t sc_size = c.is_int ? 4 : 8;
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
-    // + 4 checkpoints of strip 0's lane state (26 ints x 64 lanes) and a copy of strip 0's bottom row (fast path)
-    const uint64_t ck_bytes = b->fast ? ((uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 + (((uint64_t)max_len + 66) * 4 + 63 & ~63ull)) : 0;
+    // + checkpoints of strip 0's lane state (18 ints x 64 lanes each) and a copy of strip 0's bottom row (fast path)
+    const uint64_t ck_bytes = c.fast ? ((uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 + ((((uint64_t)max_len + 66) * 4 + 63) & ~63ull)) : 0;
     // bottom-row record: one byte per column (generic kernels) or one direction dword per block of the last strip (fast
     // path: at most (max_len + 63) / 2 + 4 blocks)
     const uint64_t zrow_bytes = std::max<uint64_t>(adv_bytes, (4ull * (((uint64_t)max_len + 63) / 2 + 8) + 63) & ~63ull);
-    b->zrow_bytes = (uint32_t)zrow_bytes;
-    b->scratch_stride = brow_bytes + adv_bytes + zrow_bytes + ck_bytes;
-    b->lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
-    if (b->fast && !pwm) { b->prof_stride = cols * 64u * ALN_FULL_R; b->lds_bytes += 4u * b->prof_stride; }
-
-    // ---- device allocations + H2D
-    uint64_t seq_bytes = 0;
-    for (size_t i = 0; i < n; ++i) {
-        if (!pwm) seq_bytes = std::max(seq_bytes, q_off[i] + q_len[i]);
-        seq_bytes = std::max(seq_bytes, t_off[i] + t_len[i]);
-    }
-    auto dmalloc = [&](void **ptr, uint64_t bytes) { return hipMalloc(ptr, std::max<uint64_t>(bytes, 256)); };
-    hipError_t e;
-#define BCHK(call) if ((e = (call)) != hipSuccess) { int st_ = fail(e, #call); batch_free(b); return st_; }
-    BCHK(dmalloc((void **)&b->d_seqs, seq_bytes + 64));
-    BCHK(dmalloc((void **)&b->d_descs, n * sizeof(PairDesc)));
-    BCHK(dmalloc((void **)&b->d_order, n * sizeof(uint32_t)));
-    BCHK(dmalloc((void **)&b->d_counter, b->counter_bytes));
-    if (b->overlap) {
-        BCHK(dmalloc((void **)&b->d_walked, 4ull * n));
-        BCHK(hipMemset(b->d_walked, 0, 4ull * n));
-        BCHK(hipStreamCreateWithFlags(&b->tb_stream, hipStreamNonBlocking));
-        BCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-        BCHK(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
-    }
-    BCHK(dmalloc((void **)&b->d_dirs, dir_total));
-    BCHK(dmalloc((void **)&b->d_results, n * sizeof(aln_pair_result)));
-    BCHK(dmalloc((void **)&b->d_tb, tb_total));
-    BCHK(dmalloc((void **)&b->d_scratch, (uint64_t)b->grid * 4 * b->scratch_stride));
-    BCHK(dmalloc((void **)&b->d_matrix, (uint64_t)rows * cols * sc_size));
-    if (want_h) BCHK(dmalloc((void **)&b->d_hmat, hm_total * sc_size));
-    if (!b->single_pairs.empty()) {
-        BCHK(dmalloc((void **)&b->d_granules, b->granule_bytes));
-        BCHK(dmalloc((void **)&b->d_advice1, 2ull * single_advice_bytes(b->single_max_n)));
-        BCHK(dmalloc((void **)&b->d_cand, 16ull * (b->single_max_n + 64)));
-        BCHK(dmalloc((void **)&b->d_ctrl, 256));
-        BCHK(dmalloc((void **)&b->d_tbmap, b->tbmap_entries * 16));
-    }
-    if (n) {
-        BCHK(hipMemcpy(b->d_seqs, seqs, seq_bytes, hipMemcpyHostToDevice));
-        BCHK(hipMemcpy(b->d_descs, b->descs.data(), n * sizeof(PairDesc), hipMemcpyHostToDevice));
-        if (!order.empty()) BCHK(hipMemcpy(b->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    if (b->is_int) {
-        std::vector<int32_t> mi(md.size());
-        for (size_t i = 0; i < md.size(); ++i) mi[i] = (int32_t)md[i];
-        BCHK(hipMemcpy(b->d_matrix, mi.data(), mi.size() * 4, hipMemcpyHostToDevice));
-    } else {
-        BCHK(hipMemcpy(b->d_matrix, md.data(), md.size() * 8, hipMemcpyHostToDevice));
-    }
-    if (pwm && b->fast) {
-        std::vector<uint32_t> words(cols);
-        for (uint32_t c = 0; c < cols; ++c) {
-            uint32_t wv = 0;
-            for (uint32_t r = 0; r < 4; ++r) wv |= ((uint32_t)(int32_t)(4 * (int32_t)md[(size_t)r * cols + c] - 2) & 0xffu) << (8 * r);
-            words[c] = wv;
-        }
-        BCHK(dmalloc((void **)&b->d_pwm_words, (uint64_t)cols * 4));
-        BCHK(hipMemcpy(b->d_pwm_words, words.data(), (size_t)cols * 4, hipMemcpyHostToDevice));
-    }
-    BCHK(hipMemset(b->d_results, 0, std::max<uint64_t>(n * sizeof(aln_pair_result), 1)));
-#undef BCHK
-    *out = b;
+    k.zrow_bytes = (uint32_t)zrow_bytes;
+    k.scratch_stride = brow_bytes + adv_bytes + zrow_bytes + ck_bytes;
+    k.lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
+    k.prof_stride = 0;
+    if (c.fast && !pwm) { k.prof_stride = cols * 64u * ALN_FULL_R; k.lds_bytes += 4u * k.prof_stride; }
     return ALN_OK;
 }
+
+// upper bounds over the chunks of a pipelined call: a slot is sized for the largest chunk the first time it is touched, so no
+// buffer grows (hipFree + hipMalloc stall every stream) in the middle of the pipeline
+struct Need {
+    uint64_t seq_span = 0, n = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, scratch = 0;
+};
+
+// device buffers of a slot for this chunk (grow-only; nothing happens once the pool is warm)
+static int slot_ensure(Slot &s, const Call &c, const Chunk &k, const Need *need = nullptr)
+{
+    int st;
+    const bool sl = s.pooled;
+#define ENS(buf, bytes) if ((st = dev_ensure(s.buf, (bytes), sl)) != ALN_OK) return st
+    if (need) {
+        ENS(seqs, need->seq_span + 64);
+        ENS(descs, need->n * sizeof(PairDesc));
+        ENS(order, need->n * sizeof(uint32_t));
+        ENS(results, need->n * sizeof(aln_pair_result));
+        ENS(dirs, need->dir_bytes);
+        ENS(tb, need->tb_bytes);
+        ENS(tags, need->tag_bytes);
+        ENS(scratch, need->scratch);
+    }
+    ENS(seqs, k.seq_span + 64);
+    ENS(descs, k.n * sizeof(PairDesc));
+    ENS(order, k.n * sizeof(uint32_t));
+    ENS(counter, k.counter_bytes);
+    if (k.overlap) {
+        const size_t before = s.walked.cap;
+        ENS(walked, 4ull * k.n);
+        if (s.walked.cap != before) s.walked_clean = false;
+        if (!s.tb_stream) HIPCHK(hipStreamCreateWithFlags(&s.tb_stream, hipStreamNonBlocking));
+        if (!s.ev_fork) HIPCHK(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+        if (!s.ev_join) HIPCHK(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
+    }
+    ENS(dirs, k.dir_bytes);
+    ENS(results, k.n * sizeof(aln_pair_result));
+    ENS(tb, k.tb_bytes);
+    ENS(tags, k.tag_bytes);
+    ENS(scratch, (uint64_t)k.grid * 4 * k.scratch_stride);
+    ENS(matrix, (uint64_t)c.rows * c.cols * (c.is_int ? 4 : 8));
+    if (c.pwm && c.fast) ENS(pwm_words, (uint64_t)c.cols * 4);
+    if (c.want_h) ENS(hmat, k.hmat_elems * (c.is_int ? 4 : 8));
+    if (!k.single_pairs.empty()) {
+        ENS(granules, k.granule_bytes);
+        ENS(advice1, 2ull * single_advice_bytes(k.single_max_n));
+        ENS(cand, 16ull * (k.single_max_n + 64));
+        ENS(ctrl, 256);
+        ENS(tbmap, k.tbmap_entries * 16);
+    }
+#undef ENS
+    // pinned staging of the small tables: descs | order | matrix | pwm words
+    const size_t meta = std::max<size_t>(k.n, need ? need->n : 0) * (sizeof(PairDesc) + 4) + (size_t)c.rows * c.cols * 8 + (size_t)c.cols * 4 + 256;
+    if ((st = pin_ensure(s.h_meta, meta)) != ALN_OK) return st;
+    if (!k.seq_direct && (st = pin_ensure(s.h_in, k.seq_span + 64)) != ALN_OK) return st;
+    return slot_init(s);
+}
+
+// H2D of one chunk on the slot's stream.  The residues come straight out of the caller's buffer (one span); the small tables
+// go through pinned memory.  Returns when the copies are queued (the span copy of pageable memory is staged by the runtime).
+static int slot_upload(Slot &s, const Call &c, const Chunk &k, const uint8_t *seqs, const uint64_t *q_off, const uint64_t *q_len,
+                       const uint64_t *t_off, const uint64_t *t_len, hipStream_t st, bool staged = false)
+{
+    uint8_t *m = s.h_meta.as<uint8_t>();
+    size_t o = 0;
+    if (k.n) {
+        memcpy(m + o, k.descs.data(), k.n * sizeof(PairDesc));
+        HIPCHK(hipMemcpyAsync(s.descs.p, m + o, k.n * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+        o += k.n * sizeof(PairDesc);
+        if (!k.order.empty()) {
+            memcpy(m + o, k.order.data(), k.order.size() * 4);
+            HIPCHK(hipMemcpyAsync(s.order.p, m + o, k.order.size() * 4, hipMemcpyHostToDevice, st));
+        }
+        o += k.n * 4;
+    }
+    o = (o + 15) & ~(size_t)15;
+    const size_t nm = c.md.size();
+    if (c.is_int) {
+        int32_t *mi = reinterpret_cast<int32_t *>(m + o);
+        for (size_t i = 0; i < nm; ++i) mi[i] = (int32_t)c.md[i];
+        HIPCHK(hipMemcpyAsync(s.matrix.p, mi, nm * 4, hipMemcpyHostToDevice, st));
+    } else {
+        memcpy(m + o, c.md.data(), nm * 8);
+        HIPCHK(hipMemcpyAsync(s.matrix.p, m + o, nm * 8, hipMemcpyHostToDevice, st));
+    }
+    o += nm * 8;
+    if (c.pwm && c.fast) {
+        uint32_t *words = reinterpret_cast<uint32_t *>(m + o);
+        for (uint32_t x = 0; x < c.cols; ++x) {
+            uint32_t wv = 0;
+            for (uint32_t r = 0; r < 4; ++r) wv |= ((uint32_t)(int32_t)(4 * (int32_t)c.md[(size_t)r * c.cols + x] - 2) & 0xffu) << (8 * r);
+            words[x] = wv;
+        }
+        HIPCHK(hipMemcpyAsync(s.pwm_words.p, words, (size_t)c.cols * 4, hipMemcpyHostToDevice, st));
+    }
+    if (k.seq_span) {
+        if (k.seq_direct) {
+            HIPCHK(hipMemcpyAsync(s.seqs.p, seqs + k.seq_lo, k.seq_span, hipMemcpyHostToDevice, st));
+        } else {
+            uint8_t *h = s.h_in.as<uint8_t>();
+            for (size_t i = 0; i < k.n && !staged; ++i) {     // staged: the caller has filled h_in already (aln_align_pair)
+                const size_t g = k.first + i;
+                if (!c.pwm && q_len[g]) memcpy(h + k.descs[i].q_off, seqs + q_off[g], q_len[g]);
+                if (t_len[g]) memcpy(h + k.descs[i].t_off, seqs + t_off[g], t_len[g]);
+            }
+            HIPCHK(hipMemcpyAsync(s.seqs.p, h, k.seq_span, hipMemcpyHostToDevice, st));
+        }
+    }
+    return ALN_OK;
+}
+
+// All kernels of one chunk, asynchronous on `st`: validation of the residue codes, fill (+ exact re-fills), traceback.
+// ev (optional): three timing events (fill start, fill end, traceback end).
+// fill_after (optional): an event the fill has to wait for (pipelined calls: the fill of the chunk two before, see below).
+static int slot_launch(aln_ctx *ctx, Slot &s, const Call &c, const Chunk &k, hipStream_t st, hipEvent_t *ev, uint32_t *fill_launches,
+                       hipEvent_t fill_after = nullptr)
+{
+    (void)ctx;
+    if (fill_launches) *fill_launches = 0;
+    if (k.n == 0) return ALN_OK;
+    HIPCHK(hipMemsetAsync(s.counter.p, 0, k.counter_bytes, st));
+    // residue codes outside the matrix: the batch fill kernels check the pairs they take; the single-pair route reads the status
+    // from the descriptor, so its pairs are checked by a kernel of their own in front
+    if (!k.single_pairs.empty())
+        aln_launch_validate(s.seqs.as<uint8_t>(), s.descs.as<PairDesc>(), (uint32_t)k.n, c.rows, c.cols, c.pwm ? 1 : 0, st);
+    FillArgs fa{};
+    fa.seqs = s.seqs.as<uint8_t>(); fa.descs = s.descs.as<PairDesc>(); fa.order = s.order.as<uint32_t>(); fa.n_pairs = (uint32_t)k.n_small;
+    fa.counter = s.counter.as<uint32_t>(); fa.dirs = s.dirs.as<uint8_t>(); fa.results = s.results.as<aln_pair_result>();
+    fa.scratch = s.scratch.as<uint8_t>(); fa.scratch_stride = k.scratch_stride; fa.max_len = k.max_len; fa.zrow_bytes = k.zrow_bytes;
+    fa.matrix = s.matrix.p; fa.rows = c.rows; fa.cols = c.cols; fa.prof_stride = k.prof_stride;
+    fa.del = c.p.del; fa.ext = c.p.ext; fa.semantics = c.semantics;
+    fa.max_passes = c.p.max_passes; fa.force_serial = c.p.force_serial;
+    fa.no_repair = getenv("ALN_NO_REPAIR") ? 1u : 0u;
+    fa.max_cells = k.max_cells;
+    fa.store_dirs = c.store_dirs ? 1u : 0u;
+    fa.pwm = c.pwm ? 1u : 0u;
+    fa.pwm_words = s.pwm_words.as<uint32_t>();
+    fa.hmat = c.want_h ? s.hmat.p : nullptr; fa.blank = c.p.blank_code;
+    if (fill_after) HIPCHK(hipStreamWaitEvent(st, fill_after, 0));
+    if (ev) HIPCHK(hipEventRecord(ev[0], st));
+    uint32_t launches = 0;
+    TraceArgs ta{};
+    ta.seqs = s.seqs.as<uint8_t>(); ta.descs = s.descs.as<PairDesc>(); ta.n_pairs = (uint32_t)k.n; ta.dirs = s.dirs.as<uint8_t>();
+    ta.results = s.results.as<aln_pair_result>(); ta.tb = s.tb.as<uint8_t>(); ta.tags = s.tags.as<uint8_t>();
+    ta.semantics = c.semantics; ta.blank = c.p.blank_code; ta.pwm = c.pwm ? 1 : 0;
+    const bool overlap = k.overlap;
+    if (overlap) {
+        if (!s.walked_clean) { HIPCHK(hipMemsetAsync(s.walked.p, 0, s.walked.cap, st)); s.walked_clean = true; s.epoch = 0; }
+        fa.doneq = s.counter.as<uint32_t>() + 64;
+        ta.walked = s.walked.as<uint32_t>(); ta.epoch = ++s.epoch; ta.n_order = (uint32_t)k.n_small;
+        ta.doneq = s.counter.as<uint32_t>() + 64; ta.head = s.counter.as<uint32_t>() + 2; ta.wait_ticks = 50000000ull;   // 0.5 s
+        if (const char *w = getenv("ALN_TB_WAIT_US")) ta.wait_ticks = 100ull * strtoull(w, nullptr, 10);   // testing: 0 = give up at once
+        HIPCHK(hipEventRecord(s.ev_fork, st));                                // after the memsets, before the fill
+    }
+    if (k.n_small) {
+        aln_launch_fill(&fa, c.is_int ? 1 : 0, c.fast ? 1 : 0, k.grid, k.lds_bytes, st);
+        HIPCHK(hipGetLastError());
+        launches = 1;
+    }
+    if (overlap) {                                                            // submitted after the fill, runs beside it
+        HIPCHK(hipStreamWaitEvent(s.tb_stream, s.ev_fork, 0));
+        aln_launch_traceback_overlap(&ta, k.tb_waves, s.tb_stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s.ev_join, s.tb_stream));
+    }
+    for (size_t j = 0; j < k.single_pairs.size(); ++j) {
+        const PairDesc &d = k.descs[k.single_pairs[j]];
+        SingleArgs sa{};
+        sa.seqs = s.seqs.as<uint8_t>(); sa.descs = s.descs.as<PairDesc>(); sa.pair = k.single_pairs[j]; sa.dirs = s.dirs.as<uint8_t>();
+        sa.results = s.results.as<aln_pair_result>(); sa.granules = s.granules.as<uint32_t>();
+        sa.gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
+        sa.advice = s.advice1.as<uint8_t>(); sa.zrow = s.advice1.as<uint8_t>() + single_advice_bytes(k.single_max_n);
+        sa.cand = s.cand.as<int32_t>(); sa.ctrl = s.ctrl.as<uint32_t>(); sa.matrix = s.matrix.p;
+        sa.rows = c.rows; sa.cols = c.cols; sa.del = c.p.del; sa.ext = c.p.ext;
+        sa.semantics = c.semantics; sa.R = k.single_r[j];
+        sa.ns = (d.M + 64 * sa.R - 1) / (64 * sa.R);
+        sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
+        sa.store_dirs = c.store_dirs ? 1u : 0u;
+        { const char *td = getenv("ALN_TEST_DROP_STRIP"); sa.test_drop = td ? (uint32_t)atoi(td) : 0u; }
+        sa.max_passes = sa.hazard ? std::min<uint32_t>(c.p.max_passes ? c.p.max_passes : 4u, 12u) : 1u;
+        aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), st);
+        // the granule rows must read "not yet produced" before a pass: one memset here, later passes are zeroed by the
+        // finalize kernel that arms them
+        HIPCHK(hipMemsetAsync(s.granules.p, 0, (size_t)sa.ns * sa.gstride * 4, st));
+        for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
+            sa.pass = pass;
+            aln_launch_single(&sa, d.N, pass + 1 == sa.max_passes ? 1 : 0, st);
+            launches++;
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[1], st));
+    if (s.ev_fill) HIPCHK(hipEventRecord(s.ev_fill, st));
+    if (c.want_tb && c.store_dirs) {
+        if (overlap) HIPCHK(hipStreamWaitEvent(st, s.ev_join, 0));
+        aln_launch_traceback(&ta, st);      // every pair except those in the uniform-R layout (handled below)
+        for (size_t j = 0; j < k.single_pairs.size(); ++j) {
+            const PairDesc &d = k.descs[k.single_pairs[j]];
+            TraceSingleArgs tsa{};
+            tsa.seqs = s.seqs.as<uint8_t>(); tsa.descs = s.descs.as<PairDesc>(); tsa.pair = k.single_pairs[j]; tsa.dirs = s.dirs.as<uint8_t>();
+            tsa.results = s.results.as<aln_pair_result>(); tsa.tb = s.tb.as<uint8_t>(); tsa.tags = s.tags.as<uint8_t>();
+            tsa.semantics = c.semantics;
+            tsa.R = k.single_r[j]; tsa.ns = (d.M + 64 * tsa.R - 1) / (64 * tsa.R);
+            tsa.map = s.tbmap.as<uint4>(); tsa.seg = s.tbmap.as<uint4>() + (uint64_t)tsa.ns * (d.N + 1);
+            aln_launch_traceback_single(&tsa, d.N, st);
+            aln_launch_traceback_expand_single(&ta, tsa.pair, st);
+        }
+        aln_launch_traceback_expand(&ta, st);
+        HIPCHK(hipGetLastError());
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[2], st));
+    if (fill_launches) *fill_launches = launches;
+    return ALN_OK;
+}
+
+// D2H of one chunk on `st`, then a stream sync: summaries into results[first ..], strings into tb_buf.  When the caller's
+// tb_off is the documented cumulative layout the chunk's strings are ONE span of tb_buf and are copied there directly;
+// any other layout goes through pinned staging and one memcpy per string.
+static int slot_download(Slot &s, const Call &c, const Chunk &k, hipStream_t st, aln_pair_result *results, uint8_t *tb_buf,
+                         const uint64_t *tb_off)
+{
+    if (k.n == 0) return ALN_OK;
+    HIPCHK(hipMemcpyAsync(results + k.first, s.results.p, k.n * sizeof(aln_pair_result), hipMemcpyDeviceToHost, st));
+    const bool want = tb_buf && tb_off && c.store_dirs && c.want_tb && k.tb_bytes;
+    bool direct = want;
+    if (want) {
+        const uint64_t base = tb_off[k.first];
+        for (size_t i = 0; i < k.n && direct; ++i) direct = tb_off[k.first + i] - base == k.descs[i].tb_off && tb_off[k.first + i] >= base;
+        if (direct) HIPCHK(hipMemcpyAsync(tb_buf + base, s.tb.p, k.tb_bytes, hipMemcpyDeviceToHost, st));
+        else {
+            int e = pin_ensure(s.h_out, k.tb_bytes);
+            if (e != ALN_OK) return e;
+            HIPCHK(hipMemcpyAsync(s.h_out.p, s.tb.p, k.tb_bytes, hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (want && !direct) {
+        const uint8_t *h = s.h_out.as<uint8_t>();
+        for (size_t i = 0; i < k.n; ++i) {
+            const PairDesc &d = k.descs[i];
+            const aln_pair_result &r = results[k.first + i];
+            if (r.status != ALN_OK) continue;
+            const uint64_t cap = (uint64_t)d.N + d.M + 2;
+            uint8_t *dst = tb_buf + tb_off[k.first + i];
+            if (c.pwm) {   // u32 column numbers, then the residue string
+                memcpy(dst, h + d.tb_off, 4ull * r.aln_len);
+                memcpy(dst + 4 * cap, h + d.tb_off + 4 * cap, r.aln_len);
+            } else {
+                memcpy(dst, h + d.tb_off, r.aln_len);
+                memcpy(dst + cap, h + d.tb_off + cap, r.aln_len);
+            }
+        }
+    }
+    return ALN_OK;
+}
+
+// ---------------------------------------------------------------- chunking of a batch call
+// Chunks are ranges of the caller's pair order, between 5e9 and 1.6e10 cells each (1.4-4.6 GB of packed directions, 2-6 ms
+// of fill): small enough that the first upload and the last traceback + download -- the only stages nothing overlaps -- are a
+// few per cent of a large call, large enough that a chunk fills the chip and that its largest pairs (a 2000 x 2000 pair takes
+// ~3 ms on its wave whatever else runs) do not outlast it by much.  ALN_CHUNK_CELLS overrides.
+// Measured (profiles/r02_e2e_chunking.txt): C5 100 000 pairs (47.3 ms resident): 30 chunks 60 ms, 16 chunks 54 ms, 8 chunks 52 ms;
+// 25 000 pairs: 6 chunks 18.2 ms, 2-4 chunks 16.6-17.1, one chunk 21.1; 12 500 pairs: 7 chunks 15.6 ms, 3 chunks 9.7, one 10.7.
+static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_len, size_t n, std::vector<std::pair<size_t, size_t>> &out)
+{
+    out.clear();
+    double total = 0;
+    for (size_t i = 0; i < n; ++i) total += (double)(c.pwm ? c.cols : q_len[i]) * (double)t_len[i];
+    double target = std::min(1.6e10, std::max(5.0e9, total / 4.0));
+    if (const char *e = getenv("ALN_CHUNK_CELLS")) target = std::max(1.0, atof(e));
+    if (total <= 1.5 * target) { out.emplace_back(0, n); return; }
+    size_t first = 0;
+    double acc = 0;
+    for (size_t i = 0; i < n; ++i) {
+        acc += (double)(c.pwm ? c.cols : q_len[i]) * (double)t_len[i];
+        if (acc >= target || i + 1 - first >= (1u << 22)) { out.emplace_back(first, i + 1 - first); first = i + 1; acc = 0; }
+    }
+    if (first < n) {
+        // a short tail joins the chunk before it
+        if (!out.empty() && acc < 0.25 * target) out.back().second += n - first;
+        else out.emplace_back(first, n - first);
+    }
+}
+
+extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
+                               const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
+                               aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off)
+{
+    if (!ctx || !params || (n_pairs && (!seqs || !q_off || !q_len || !t_off || !t_len || !results))) { g_err = "null argument"; return ALN_ERR_INVALID_ARGUMENT; }
+    Call c;
+    int st = call_init(c, params, q_len, t_len, n_pairs, false);
+    if (st != ALN_OK) return st;
+    if (n_pairs == 0) return ALN_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<std::pair<size_t, size_t>> ranges;
+    make_chunks(c, q_len, t_len, n_pairs, ranges);
+    const size_t nc = ranges.size();
+
+    Slot *slots[ALN_POOL_SLOTS];
+    const int ns = pool_lease(ctx, (int)std::min<size_t>(nc, nc > 1 ? ALN_POOL_SLOTS : 1), slots);
+    struct Release { aln_ctx *c; Slot **s; int n; ~Release() { pool_release(c, s, n); } } rel{ctx, slots, ns};
+
+    Need need;
+    if (nc > 1) {
+        const uint64_t sc = c.is_int ? 4 : 8;
+        for (const auto &r : ranges) {
+            uint64_t lo = ~0ull, hi = 0, sum = 0, dirs = 0, tb = 0, tags = 0, mlen = 1;
+            for (size_t i = r.first; i < r.first + r.second; ++i) {
+                const uint64_t N = c.pwm ? c.cols : q_len[i], M = t_len[i], cap = N + M + 2;
+                if (!c.pwm && N) { lo = std::min(lo, q_off[i]); hi = std::max(hi, q_off[i] + N); sum += N; }
+                if (M) { lo = std::min(lo, t_off[i]); hi = std::max(hi, t_off[i] + M); sum += M; }
+                if (c.store_dirs) { tb += c.pwm ? ((5 * cap + 3) & ~3ull) : 2 * cap; tags += (cap + 3) & ~3ull; }
+                if (N && M && c.store_dirs) dirs += aln_dir_bytes((uint32_t)N, (uint32_t)M);
+                if (N && M) mlen = std::max(mlen, std::max(N, M));
+            }
+            const uint64_t span = hi > lo ? ((hi - lo) <= 2 * sum + 65536 ? hi - lo : sum) : 0;
+            need.seq_span = std::max(need.seq_span, span);
+            need.n = std::max<uint64_t>(need.n, r.second);
+            need.dir_bytes = std::max(need.dir_bytes, dirs);
+            need.tb_bytes = std::max(need.tb_bytes, tb);
+            need.tag_bytes = std::max(need.tag_bytes, tags);
+            // per wave: boundary row, advice, bottom-row record, checkpoints (chunk_plan)
+            const uint64_t stride = (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull) +
+                                    std::max<uint64_t>((mlen + 66 + 63) & ~63ull, (4 * ((mlen + 63) / 2 + 8) + 63) & ~63ull) +
+                                    (c.fast ? ((uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 + (((mlen + 66) * 4 + 63) & ~63ull)) : 0);
+            need.scratch = std::max(need.scratch, (uint64_t)ctx->cus * 4 * 4 * stride);
+        }
+    }
+
+    if (nc == 1) {                                   // one chunk: everything on the caller's thread
+        Chunk k;
+        Slot &s = *slots[0];
+        if ((st = chunk_plan(ctx, c, q_off, q_len, t_off, t_len, 0, n_pairs, true, k)) != ALN_OK) return st;
+        if ((st = slot_ensure(s, c, k)) != ALN_OK) return st;
+        if ((st = slot_upload(s, c, k, seqs, q_off, q_len, t_off, t_len, s.stream)) != ALN_OK) return st;
+        if ((st = slot_launch(ctx, s, c, k, s.stream, nullptr, nullptr)) != ALN_OK) { (void)hipStreamSynchronize(s.stream); return st; }
+        return slot_download(s, c, k, s.stream, results, tb_buf, tb_off);
+    }
+
+    // ---- pipeline: this thread plans, uploads and launches chunk after chunk; a second thread waits for each chunk's
+    // kernels and copies its results back; a slot is reused once its previous chunk has been fetched.
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<size_t> ready;          // chunks launched, to be fetched, in order
+        std::vector<char> slot_free;
+        bool done_issuing = false;
+        int status = ALN_OK;
+        std::string err;
+    } sh;
+    sh.slot_free.assign(ns, 1);
+    std::vector<Chunk> chunks(nc);
+    size_t depth = 3;
+    if (const char *e = getenv("ALN_FILL_DEPTH")) depth = std::max(1, atoi(e));
+    const int dev = ctx->device;
+    std::thread fetcher([&] {
+        (void)hipSetDevice(dev);
+        for (;;) {
+            size_t ci;
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv.wait(lk, [&] { return !sh.ready.empty() || sh.done_issuing; });
+                if (sh.ready.empty()) return;
+                ci = sh.ready.front();
+                sh.ready.pop_front();
+            }
+            const int si = (int)(ci % (size_t)ns);
+            Slot &s = *slots[si];
+            int e = slot_download(s, c, chunks[ci], s.stream, results, tb_buf, tb_off);
+            {
+                std::lock_guard<std::mutex> lk(sh.mu);
+                if (e != ALN_OK && sh.status == ALN_OK) { sh.status = e; sh.err = g_err; }
+                sh.slot_free[si] = 1;
+                chunks[ci] = Chunk();      // the plan is not needed any more
+            }
+            sh.cv.notify_all();
+        }
+    });
+    for (size_t ci = 0; ci < nc && st == ALN_OK; ++ci) {
+        Chunk &k = chunks[ci];
+        // (walk waves beside the LAST chunk's own fill, as a staged batch has them, were measured: 53.7 ms against 52.0 without)
+        st = chunk_plan(ctx, c, q_off, q_len, t_off, t_len, ranges[ci].first, ranges[ci].second, false, k);   // while the GPU works
+        if (st != ALN_OK) break;
+        const int si = (int)(ci % (size_t)ns);
+        {
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv.wait(lk, [&] { return sh.slot_free[si] != 0 || sh.status != ALN_OK; });
+            if (sh.status != ALN_OK) break;
+            sh.slot_free[si] = 0;
+        }
+        Slot &s = *slots[si];
+        if ((st = slot_ensure(s, c, k, &need)) != ALN_OK) break;
+        if ((st = slot_upload(s, c, k, seqs, q_off, q_len, t_off, t_len, s.stream)) != ALN_OK) break;
+        // At most `depth` fills share the chip: chunk i's fill waits for the fill of chunk i - depth.  With every slot's fill
+        // started at once the chunks run in lockstep -- they share the chip equally, reach their tails together (a chunk's
+        // largest pairs take as long as the whole chunk), then all walk and copy while nothing fills.  Fewer at a time stay
+        // staggered: the oldest is in its tail while the younger ones fill the waves it leaves free (C5, 16 chunks: depth
+        // 1: 83 ms, 2: 53.7, 3: 52.6, 4 = every slot: 56.5).
+        hipEvent_t after = (ci >= depth && ns > (int)depth) ? slots[(ci - depth) % (size_t)ns]->ev_fill : nullptr;
+        if ((st = slot_launch(ctx, s, c, k, s.stream, nullptr, nullptr, after)) != ALN_OK) break;
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.ready.push_back(ci);
+        }
+        sh.cv.notify_all();
+    }
+    const std::string my_err = g_err;
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        sh.done_issuing = true;
+    }
+    sh.cv.notify_all();
+    fetcher.join();
+    for (int i = 0; i < ns; ++i) (void)hipStreamSynchronize(slots[i]->stream);
+    if (st != ALN_OK) { g_err = my_err; return st; }
+    if (sh.status != ALN_OK) { g_err = sh.err; return sh.status; }
+    return ALN_OK;
+}
+
+// ---------------------------------------------------------------- staged batch: one chunk resident in a private slot
+struct aln_batch {
+    aln_ctx *ctx = nullptr;
+    Call call;
+    Chunk k;
+    Slot *slot = nullptr;
+    hipStream_t last_stream = nullptr;
+    // timing ring: one event triple per run (fill start, fill end, traceback end), recorded on the launch stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    uint32_t ev_runs = 0;
+    uint32_t fill_launches = 0;
+};
+
+static void batch_free(aln_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    slot_destroy(b->slot);
+    delete b;
+}
+
+extern "C" void aln_batch_destroy(aln_batch *b) { batch_free(b); }
 
 extern "C" aln_batch *aln_batch_create(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs,
                                        const uint64_t *q_off, const uint64_t *q_len, const uint64_t *t_off,
                                        const uint64_t *t_len, size_t n_pairs, int *status)
 {
+    int st = ALN_OK;
     aln_batch *b = nullptr;
-    int st = batch_build(ctx, params, seqs, q_off, q_len, t_off, t_len, n_pairs, false, &b);
+    if (!ctx || !params || (n_pairs && (!seqs || !q_off || !q_len || !t_off || !t_len))) { g_err = "null argument"; st = ALN_ERR_INVALID_ARGUMENT; }
+    else {
+        b = new aln_batch();
+        b->ctx = ctx;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e != hipSuccess) st = fail(e, "hipSetDevice");
+        if (st == ALN_OK) st = call_init(b->call, params, q_len, t_len, n_pairs, false);
+        if (st == ALN_OK) st = chunk_plan(ctx, b->call, q_off, q_len, t_off, t_len, 0, n_pairs, true, b->k);
+        if (st == ALN_OK) {
+            b->slot = new Slot();
+            b->slot->pooled = false;
+            st = slot_ensure(*b->slot, b->call, b->k);
+        }
+        if (st == ALN_OK) st = slot_upload(*b->slot, b->call, b->k, seqs, q_off, q_len, t_off, t_len, b->slot->stream);
+        if (st == ALN_OK) {
+            e = hipMemsetAsync(b->slot->results.p, 0, std::max<size_t>(n_pairs * sizeof(aln_pair_result), 1), b->slot->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(b->slot->stream);
+            if (e != hipSuccess) st = fail(e, "stage");
+        }
+        if (st != ALN_OK) { batch_free(b); b = nullptr; }
+    }
     if (status) *status = st;
     return b;
 }
@@ -459,101 +970,19 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
 {
     if (!b) return ALN_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(b->ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : b->ctx->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : b->slot->stream;
     b->last_stream = s;
-    if (b->n == 0) return ALN_OK;
-    HIPCHK(hipMemsetAsync(b->d_counter, 0, b->counter_bytes, s));
-    FillArgs fa{};
-    fa.seqs = b->d_seqs; fa.descs = b->d_descs; fa.order = b->d_order; fa.n_pairs = (uint32_t)b->n_small;
-    fa.counter = b->d_counter; fa.dirs = b->d_dirs; fa.results = b->d_results;
-    fa.scratch = b->d_scratch; fa.scratch_stride = b->scratch_stride; fa.max_len = b->max_len; fa.zrow_bytes = b->zrow_bytes;
-    fa.matrix = b->d_matrix; fa.rows = b->params.rows; fa.cols = b->params.cols; fa.prof_stride = b->prof_stride;
-    fa.del = b->params.del; fa.ext = b->params.ext; fa.semantics = b->params.semantics;
-    fa.max_passes = b->params.max_passes; fa.force_serial = b->params.force_serial;
-    fa.no_repair = getenv("ALN_NO_REPAIR") ? 1u : 0u;
-    fa.max_cells = b->max_cells;
-    fa.store_dirs = b->store_dirs ? 1u : 0u;
-    fa.pwm = b->pwm ? 1u : 0u;
-    fa.pwm_words = b->d_pwm_words;
-    fa.hmat = b->d_hmat; fa.blank = b->params.blank_code;
     hipEvent_t *ev = b->timing ? &b->ev[3 * (b->ev_runs % ALN_TIMING_SLOTS)] : nullptr;
-    if (ev) HIPCHK(hipEventRecord(ev[0], s));
-    b->fill_launches = 0;
-    const uint32_t outs = b->params.outputs ? b->params.outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK);
-    TraceArgs ta{};
-    ta.seqs = b->d_seqs; ta.descs = b->d_descs; ta.n_pairs = (uint32_t)b->n; ta.dirs = b->d_dirs;
-    ta.results = b->d_results; ta.tb = b->d_tb; ta.semantics = b->params.semantics; ta.blank = b->params.blank_code; ta.pwm = b->pwm ? 1 : 0;
-    const bool overlap = b->overlap && b->store_dirs && (outs & ALN_OUT_TRACEBACK);
-    if (overlap) {
-        fa.doneq = b->d_counter + 64;
-        ta.walked = b->d_walked; ta.epoch = ++b->epoch; ta.n_order = (uint32_t)b->n_small;
-        ta.doneq = b->d_counter + 64; ta.head = b->d_counter + 2; ta.wait_ticks = 50000000ull;          // 0.5 s
-        if (const char *w = getenv("ALN_TB_WAIT_US")) ta.wait_ticks = 100ull * strtoull(w, nullptr, 10);   // testing: 0 = give up at once
-        HIPCHK(hipEventRecord(b->ev_fork, s));                               // after the memset, before the fill
-    }
-    if (b->n_small) {
-        aln_launch_fill(&fa, b->is_int ? 1 : 0, b->fast ? 1 : 0, b->grid, b->lds_bytes, s);
-        HIPCHK(hipGetLastError());
-        b->fill_launches = 1;
-    }
-    if (overlap) {                                                           // submitted after the fill, runs beside it
-        HIPCHK(hipStreamWaitEvent(b->tb_stream, b->ev_fork, 0));
-        aln_launch_traceback_overlap(&ta, b->tb_waves, b->tb_stream);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(b->ev_join, b->tb_stream));
-    }
-    for (size_t j = 0; j < b->single_pairs.size(); ++j) {
-        const PairDesc &d = b->descs[b->single_pairs[j]];
-        SingleArgs sa{};
-        sa.seqs = b->d_seqs; sa.descs = b->d_descs; sa.pair = b->single_pairs[j]; sa.dirs = b->d_dirs;
-        sa.results = b->d_results; sa.granules = b->d_granules;
-        sa.gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
-        sa.advice = b->d_advice1; sa.zrow = b->d_advice1 + single_advice_bytes(b->single_max_n);
-        sa.cand = b->d_cand; sa.ctrl = b->d_ctrl; sa.matrix = b->d_matrix;
-        sa.rows = b->params.rows; sa.cols = b->params.cols; sa.del = b->params.del; sa.ext = b->params.ext;
-        sa.semantics = b->params.semantics; sa.R = b->single_r[j];
-        sa.ns = (d.M + 64 * sa.R - 1) / (64 * sa.R);
-        sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
-        sa.store_dirs = b->store_dirs ? 1u : 0u;
-        { const char *td = getenv("ALN_TEST_DROP_STRIP"); sa.test_drop = td ? (uint32_t)atoi(td) : 0u; }
-        sa.max_passes = sa.hazard ? std::min<uint32_t>(b->params.max_passes ? b->params.max_passes : 4u, 12u) : 1u;
-        aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), s);
-        // the granule rows must read "not yet produced" before a pass: one memset here, later passes are zeroed by the
-        // finalize kernel that arms them
-        HIPCHK(hipMemsetAsync(b->d_granules, 0, (size_t)sa.ns * sa.gstride * 4, s));
-        for (uint32_t pass = 0; pass < sa.max_passes; ++pass) {
-            sa.pass = pass;
-            aln_launch_single(&sa, d.N, pass + 1 == sa.max_passes ? 1 : 0, s);
-            b->fill_launches++;
-        }
-        HIPCHK(hipGetLastError());
-    }
-    if (ev) HIPCHK(hipEventRecord(ev[1], s));
-    if ((outs & ALN_OUT_TRACEBACK) && b->store_dirs) {
-        if (overlap) HIPCHK(hipStreamWaitEvent(s, b->ev_join, 0));
-        aln_launch_traceback(&ta, s);       // every pair except those in the uniform-R layout (handled below)
-        for (size_t j = 0; j < b->single_pairs.size(); ++j) {
-            const PairDesc &d = b->descs[b->single_pairs[j]];
-            TraceSingleArgs tsa{};
-            tsa.seqs = b->d_seqs; tsa.descs = b->d_descs; tsa.pair = b->single_pairs[j]; tsa.dirs = b->d_dirs;
-            tsa.results = b->d_results; tsa.tb = b->d_tb; tsa.semantics = b->params.semantics;
-            tsa.R = b->single_r[j]; tsa.ns = (d.M + 64 * tsa.R - 1) / (64 * tsa.R);
-            tsa.map = b->d_tbmap; tsa.seg = b->d_tbmap + (uint64_t)tsa.ns * (d.N + 1);
-            aln_launch_traceback_single(&tsa, d.N, s);
-            aln_launch_traceback_expand_single(&ta, tsa.pair, s);
-        }
-        aln_launch_traceback_expand(&ta, s);
-        HIPCHK(hipGetLastError());
-    }
-    if (ev) { HIPCHK(hipEventRecord(ev[2], s)); b->ev_runs++; }
-    return ALN_OK;
+    int st = slot_launch(b->ctx, *b->slot, b->call, b->k, s, ev, &b->fill_launches);
+    if (st == ALN_OK && ev) b->ev_runs++;
+    return st;
 }
 
 extern "C" int aln_batch_sync(aln_batch *b)
 {
     if (!b) return ALN_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(b->ctx->device));
-    HIPCHK(hipStreamSynchronize(b->last_stream ? b->last_stream : b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->last_stream ? b->last_stream : b->slot->stream));
     return ALN_OK;
 }
 
@@ -582,36 +1011,18 @@ extern "C" int aln_batch_fetch(aln_batch *b, aln_pair_result *results, uint8_t *
     if (!b || !results) return ALN_ERR_INVALID_ARGUMENT;
     int st = aln_batch_sync(b);
     if (st != ALN_OK) return st;
-    if (b->n == 0) return ALN_OK;
-    HIPCHK(hipMemcpy(results, b->d_results, b->n * sizeof(aln_pair_result), hipMemcpyDeviceToHost));
-    if (tb_buf && tb_off && b->tb_bytes) {
-        std::vector<uint8_t> h(b->tb_bytes);
-        HIPCHK(hipMemcpy(h.data(), b->d_tb, b->tb_bytes, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < b->n; ++i) {
-            const PairDesc &d = b->descs[i];
-            if (results[i].status != ALN_OK) continue;
-            const uint64_t cap = (uint64_t)d.N + d.M + 2;
-            if (b->pwm) {   // u32 column numbers, then the residue string
-                memcpy(tb_buf + tb_off[i], h.data() + d.tb_off, 4ull * results[i].aln_len);
-                memcpy(tb_buf + tb_off[i] + 4 * cap, h.data() + d.tb_off + 4 * cap, results[i].aln_len);
-            } else {
-                memcpy(tb_buf + tb_off[i], h.data() + d.tb_off, results[i].aln_len);
-                memcpy(tb_buf + tb_off[i] + cap, h.data() + d.tb_off + cap, results[i].aln_len);
-            }
-        }
-    }
-    return ALN_OK;
+    return slot_download(*b->slot, b->call, b->k, b->slot->stream, results, tb_buf, tb_off);
 }
 
-extern "C" uint64_t aln_batch_cells(const aln_batch *b) { return b ? b->cells : 0; }
-extern "C" size_t aln_batch_size(const aln_batch *b) { return b ? b->n : 0; }
-extern "C" void *aln_batch_results_device(aln_batch *b) { return b ? b->d_results : nullptr; }
+extern "C" uint64_t aln_batch_cells(const aln_batch *b) { return b ? b->k.cells : 0; }
+extern "C" size_t aln_batch_size(const aln_batch *b) { return b ? b->k.n : 0; }
+extern "C" void *aln_batch_results_device(aln_batch *b) { return b ? b->slot->results.p : nullptr; }
 extern "C" uint64_t aln_batch_direction_bytes(const aln_batch *b)
 {
     if (!b) return 0;
     // bytes the fill kernel actually stores: per strip, ceil(steps / SPB) blocks of 256 B
     uint64_t total = 0;
-    for (const PairDesc &d : b->descs) {
+    for (const PairDesc &d : b->k.descs) {
         if (d.status != ALN_OK) continue;
         const uint32_t ns = aln_num_strips(d.M);
         for (uint32_t s = 0; s < ns; ++s) {
@@ -625,22 +1036,7 @@ extern "C" uint64_t aln_batch_direction_bytes(const aln_batch *b)
     return total;
 }
 
-extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
-                               const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
-                               aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off)
-{
-    aln_batch *b = nullptr;
-    int st = batch_build(ctx, params, seqs, q_off, q_len, t_off, t_len, n_pairs, false, &b);
-    if (st != ALN_OK) return st;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        st = aln_batch_run(b, nullptr);
-        if (st == ALN_OK) st = aln_batch_fetch(b, results, tb_buf, tb_off);
-    }
-    batch_free(b);
-    return st;
-}
-
+// ---------------------------------------------------------------- one pair, blocking
 extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint8_t *query, size_t N,
                               const uint8_t *target, size_t M, aln_pair_result *out, uint8_t *q_aln, uint8_t *t_aln,
                               uint8_t *directions, double *h_matrix)
@@ -649,58 +1045,68 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
     const bool pwm = params->semantics == ALN_PWM_LOCAL;
     if (pwm) { N = params->cols; query = nullptr; }          // the columns are the PWM positions (pwm/mod.rs:44-46)
     const size_t nq = pwm ? 0 : N;
-    std::vector<uint8_t> seqs(nq + M + 1);
-    if (nq) memcpy(seqs.data(), query, nq);
-    if (M) memcpy(seqs.data() + nq, target, M);
-    const uint64_t qo = 0, ql = N, to = nq, tl = M;
     aln_params p = *params;
     p.outputs = (params->outputs ? params->outputs : (ALN_OUT_SCORE | ALN_OUT_TRACEBACK));
     if (q_aln && t_aln) p.outputs |= ALN_OUT_TRACEBACK;
     if (directions) p.outputs |= ALN_OUT_DIRECTIONS;
-    aln_batch *b = nullptr;
-    int st = batch_build(ctx, &p, seqs.data(), &qo, &ql, &to, &tl, 1, h_matrix != nullptr, &b);
+    const uint64_t qo = 0, ql = N, to = nq, tl = M;
+    Call c;
+    int st = call_init(c, &p, &ql, &tl, 1, h_matrix != nullptr);
     if (st != ALN_OK) { memset(out, 0, sizeof *out); out->status = st; return st; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    st = aln_batch_run(b, nullptr);
+    HIPCHK(hipSetDevice(ctx->device));
+    Slot *sl[1];
+    pool_lease(ctx, 1, sl);
+    struct Release { aln_ctx *c; Slot **s; ~Release() { pool_release(c, s, 1); } } rel{ctx, sl};
+    Slot &s = *sl[0];
+    Chunk k;
+    if ((st = chunk_plan(ctx, c, &qo, &ql, &to, &tl, 0, 1, false, k)) != ALN_OK) return st;
+    k.seq_direct = false;                                    // query and target are two caller buffers: gathered into staging
+    k.seq_span = nq + M;
+    k.descs[0].q_off = 0; k.descs[0].t_off = nq;
+    if ((st = slot_ensure(s, c, k)) != ALN_OK) return st;
+    {   // the gather of slot_upload, from two pointers
+        uint8_t *h = s.h_in.as<uint8_t>();
+        if (nq) memcpy(h, query, nq);
+        if (M) memcpy(h + nq, target, M);
+    }
+    if ((st = slot_upload(s, c, k, nullptr, &qo, &ql, &to, &tl, s.stream, true)) != ALN_OK) return st;
+    if ((st = slot_launch(ctx, s, c, k, s.stream, nullptr, nullptr)) != ALN_OK) { (void)hipStreamSynchronize(s.stream); return st; }
     const size_t cap = N + M + 2;
-    std::vector<uint8_t> tb((pwm ? 5 : 2) * cap + 8);
-    const uint64_t tbo = 0;
-    if (st == ALN_OK) st = aln_batch_fetch(b, out, tb.data(), &tbo);
-    if (st == ALN_OK && out->status == ALN_OK) {
-        if (q_aln && t_aln) {
+    const uint64_t cells = (uint64_t)(N + 1) * (M + 1);
+    const bool ok_shape = k.descs[0].status == ALN_OK;
+    if (directions && ok_shape) {
+        if ((st = dev_ensure(s.unpack, cells, true)) != ALN_OK) return st;
+        aln_launch_unpack(s.dirs.as<uint8_t>(), s.descs.as<PairDesc>(), 0, c.semantics, s.unpack.as<uint8_t>(), cells, s.stream);
+    }
+    // summary + strings: the strings of one pair are fetched through pinned staging and handed out as two buffers
+    HIPCHK(hipMemcpyAsync(out, s.results.p, sizeof *out, hipMemcpyDeviceToHost, s.stream));
+    const bool want_tb = q_aln && t_aln && c.want_tb && k.tb_bytes;
+    if (want_tb) {
+        if ((st = pin_ensure(s.h_out, k.tb_bytes)) != ALN_OK) return st;
+        HIPCHK(hipMemcpyAsync(s.h_out.p, s.tb.p, k.tb_bytes, hipMemcpyDeviceToHost, s.stream));
+    }
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (out->status == ALN_OK && ok_shape) {
+        if (want_tb) {
+            const uint8_t *h = s.h_out.as<uint8_t>();
             if (pwm) {
-                memcpy(q_aln, tb.data(), 4ull * out->aln_len);          // uint32 PWM column numbers
-                memcpy(t_aln, tb.data() + 4 * cap, out->aln_len);
+                memcpy(q_aln, h, 4ull * out->aln_len);          // uint32 PWM column numbers
+                memcpy(t_aln, h + 4 * cap, out->aln_len);
             } else {
-                memcpy(q_aln, tb.data(), out->aln_len);
-                memcpy(t_aln, tb.data() + cap, out->aln_len);
+                memcpy(q_aln, h, out->aln_len);
+                memcpy(t_aln, h + cap, out->aln_len);
             }
         }
-        const uint64_t cells = (uint64_t)(N + 1) * (M + 1);
-        if (directions) {
-            uint8_t *d_out = nullptr;
-            hipError_t e = hipMalloc((void **)&d_out, cells);
-            if (e != hipSuccess) { st = fail(e, "hipMalloc(directions)"); }
-            else {
-                aln_launch_unpack(b->d_dirs, b->d_descs, 0, b->params.semantics, d_out, cells, b->ctx->stream);
-                e = hipStreamSynchronize(b->ctx->stream);
-                if (e == hipSuccess) e = hipMemcpy(directions, d_out, cells, hipMemcpyDeviceToHost);
-                if (e != hipSuccess) st = fail(e, "unpack directions");
-                (void)hipFree(d_out);
-            }
-        }
-        if (h_matrix && st == ALN_OK) {
-            if (b->is_int) {
+        if (directions) HIPCHK(hipMemcpy(directions, s.unpack.p, cells, hipMemcpyDeviceToHost));
+        if (h_matrix) {
+            if (c.is_int) {
                 std::vector<int32_t> hi(cells);
-                hipError_t e = hipMemcpy(hi.data(), b->d_hmat, cells * 4, hipMemcpyDeviceToHost);
-                if (e != hipSuccess) st = fail(e, "fetch H");
-                else for (uint64_t i = 0; i < cells; ++i) h_matrix[i] = (double)hi[i];
+                HIPCHK(hipMemcpy(hi.data(), s.hmat.p, cells * 4, hipMemcpyDeviceToHost));
+                for (uint64_t i = 0; i < cells; ++i) h_matrix[i] = (double)hi[i];
             } else {
-                hipError_t e = hipMemcpy(h_matrix, b->d_hmat, cells * 8, hipMemcpyDeviceToHost);
-                if (e != hipSuccess) st = fail(e, "fetch H");
+                HIPCHK(hipMemcpy(h_matrix, s.hmat.p, cells * 8, hipMemcpyDeviceToHost));
             }
         }
     }
-    batch_free(b);
-    return st != ALN_OK ? st : out->status;
+    return out->status;
 }

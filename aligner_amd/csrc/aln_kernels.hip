@@ -574,11 +574,22 @@ __device__ __forceinline__ void pair_done(const FillArgs &a, int lane, uint32_t 
         __hip_atomic_store(a.doneq + pos, pair + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// The reference indexes the matrix with every residue (simple/mod.rs:85,198) and panics on a code outside it.  The wave that
+// takes a pair scans both sequences first (the codes are on their way into L2 anyway; a few microseconds per pair) and turns
+// that into the pair's status: the host never touches the residues of a batch.
+__device__ __forceinline__ bool pair_codes_ok(const uint8_t *seqs, const PairDesc &d, uint32_t rows, uint32_t cols, bool pwm, int lane)
+{
+    const uint8_t *q = seqs + d.q_off, *t = seqs + d.t_off;
+    uint32_t worst_q = 0, worst_t = 0;
+    if (!pwm) for (uint32_t i = (uint32_t)lane; i < d.N; i += 64u) worst_q = max(worst_q, (uint32_t)q[i]);
+    for (uint32_t i = (uint32_t)lane; i < d.M; i += 64u) worst_t = max(worst_t, (uint32_t)t[i]);
+    return !__any(worst_q >= cols || worst_t >= rows);
+}
 __device__ __forceinline__ void skip_invalid(aln_pair_result &res, int status, int lane)
 {
     if (lane == 0) {
         res.f = 0.0; res.score = 0.0; res.end_y = res.end_x = res.start_y = res.start_x = 0;
-        res.aln_len = 0; res.status = status; res.passes = 0; res.flags = 0;
+        res.aln_len = 0; res.status = status == ALN_PRE_EMPTY_OK ? ALN_OK : status; res.passes = 0; res.flags = 0;
     }
 }
 
@@ -622,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void aln_fill_kernel(FillArgs a)
         PairDesc &desc = a.descs[pair];
         aln_pair_result &res = a.results[pair];
         if (desc.status != ALN_OK) skip_invalid(res, desc.status, w.lane);
+        else if (!pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, w.lane)) skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, w.lane);
         else do_pair<SC, SEM>(w, a, desc, res);
         pair_done(a, w.lane, pair, true);
     }
@@ -663,6 +675,7 @@ void aln_fill_fast_kernel(FillArgs a)
         aln_pair_result &res = a.results[pair];
         bool plain = false;
         if (desc.status != ALN_OK) skip_invalid(res, desc.status, in.lane);
+        else if (!pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, in.lane)) skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, in.lane);
         else {
             set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
             plain = do_pair_fast<SEM, PWM>(in, a, desc, res, (int)a.del, (int)a.ext);
@@ -829,12 +842,35 @@ __global__ __launch_bounds__(64) void aln_single_serial_kernel(SingleArgs a)
     write_result<SEM>(res, (double)w.bv, w.by, w.bx, (double)w.corner, desc.N, desc.M, a.ctrl[15] | 0x80u, 1u | 2u);
 }
 
-// arms pass 0 and clears the advice / bottom-row bytes
+// arms pass 0 and clears the advice / bottom-row bytes.  A pair the validation kernel rejected (a residue code outside the
+// matrix) is not armed: every later kernel of the route returns at once, and the summary carries the status.
 extern "C" __global__ void aln_single_init_kernel(SingleArgs a, uint32_t n_bytes)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int st = a.descs[a.pair].status;
     if (i < n_bytes) { a.advice[i] = 0; a.zrow[i] = 0; }
-    if (i < 16) a.ctrl[i] = (i == 1) ? 1u : 0u;
+    if (i < 16) a.ctrl[i] = (i == 1 && st == ALN_OK) ? 1u : 0u;
+    if (i == 0 && st != ALN_OK) skip_invalid(a.results[a.pair], st, 0);
+}
+
+// ---------------------------------------------------------------- residue-code validation
+// The reference indexes the matrix with every residue (simple/mod.rs:85,198) and panics on a code outside it; here one wave
+// per pair scans both sequences and turns that into the pair's status (ALN_ERR_CODE_OUT_OF_RANGE).  The batch fill kernels do
+// this themselves (pair_codes_ok); this kernel runs in front of the single-pair route, whose kernels take the status from
+// the descriptor.
+extern "C" __global__ __launch_bounds__(256) void aln_validate_kernel(const uint8_t *seqs, PairDesc *descs, uint32_t n_pairs,
+                                                                      uint32_t rows, uint32_t cols, uint32_t pwm)
+{
+    const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= n_pairs) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    PairDesc &d = descs[pair];
+    if (d.status != ALN_OK) return;
+    const uint8_t *q = seqs + d.q_off, *t = seqs + d.t_off;
+    uint32_t bad = 0;
+    if (!pwm) for (uint32_t i = lane; i < d.N; i += 64u) bad |= (q[i] >= cols) ? 1u : 0u;
+    for (uint32_t i = lane; i < d.M; i += 64u) bad |= (t[i] >= rows) ? 1u : 0u;
+    if (__any(bad != 0) && lane == 0) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
 }
 
 // ---------------------------------------------------------------- traceback
@@ -910,8 +946,7 @@ __device__ __forceinline__ void tb_walk_pair(const TraceArgs &a, uint32_t pair)
     aln_pair_result &res = a.results[pair];
     if (res.status != ALN_OK) return;
     if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) return;      // large pairs: aln_tb_single_* kernels
-    const uint32_t cap = d.N + d.M + 2;
-    uint8_t *__restrict__ ops = a.tb + d.tb_off + (a.pwm ? 5ull : 2ull) * cap;
+    uint8_t *__restrict__ ops = a.tags + d.tag_off;
     const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
     const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
     const uint32_t ey = res.end_y, ex = res.end_x, N = d.N;
@@ -981,6 +1016,8 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= a.n_pairs) return;
     if (a.walked && a.walked[pair] == a.epoch) return;  // the overlap kernel has been here
+    // latency-bound and light on issue slots: ahead of the fill waves (of the next chunk) it shares a SIMD with
+    __builtin_amdgcn_s_setprio(3);
     tb_walk_pair(a, pair);
 }
 // The walks are latency-bound and the fill is issue-bound: this kernel runs BESIDE the fill kernel (second stream; the host
@@ -1220,7 +1257,7 @@ extern "C" __global__ __launch_bounds__(256) void aln_tb_single_segments_kernel(
     if (sg.w == 0) return;
     const uint32_t lgR = 31u - (uint32_t)__builtin_clz(a.R), rows = 64u << lgR;
     const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
-    uint8_t *ops = a.tb + d.tb_off + 2ull * (d.N + d.M + 2) + sg.z;
+    uint8_t *ops = a.tags + d.tag_off + sg.z;
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
     uint32_t cy = sg.x, cx = sg.y, steps = 0;
     const uint32_t y0 = s * rows;
@@ -1252,7 +1289,7 @@ extern "C" __global__ __launch_bounds__(1024) void aln_tb_single_expand_kernel(T
     const uint32_t cap = d.N + d.M + 2;
     uint8_t *__restrict__ qa = a.tb + d.tb_off;
     uint8_t *__restrict__ ta = qa + cap;
-    const uint8_t *__restrict__ ops = a.tb + d.tb_off + 2ull * cap;
+    const uint8_t *__restrict__ ops = a.tags + d.tag_off;
     const uint32_t len = res.aln_len - 1u;
     const uint32_t per = (len + 1023u) / 1024u;
     const uint32_t lo = min(len, tid * per), hi = min(len, lo + per);
@@ -1287,10 +1324,13 @@ extern "C" __global__ __launch_bounds__(1024) void aln_tb_single_expand_kernel(T
 // Pass 2, one wave per pair: turns the tag string into the two aligned code strings in final (forward) order.
 // Position j of the output is step (len - 1 - j); its cell is the stop cell plus the moves of the steps after it, i.e.
 // a prefix sum over the tags -- each lane sums its contiguous slice, one wave scan, then each lane replays its slice.
-extern "C" __global__ __launch_bounds__(256) void aln_traceback_expand_kernel(TraceArgs a)
+// 32 VGPRs (the attribute counts pairs): one wave of this kernel fits beside a full grid of the fill kernel (3 x 160 of a SIMD's
+// 512 registers), so the strings of chunk i are written while chunk i+1 fills instead of waiting for a workgroup slot.
+extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_num_vgpr(16))) void aln_traceback_expand_kernel(TraceArgs a)
 {
     const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pair >= a.n_pairs) return;
+    constexpr int G = 2;
     const int lane = threadIdx.x & 63;
     const PairDesc &d = a.descs[pair];
     const aln_pair_result &res = a.results[pair];
@@ -1301,38 +1341,38 @@ extern "C" __global__ __launch_bounds__(256) void aln_traceback_expand_kernel(Tr
     const uint32_t cap = d.N + d.M + 2;
     uint8_t *__restrict__ qa = a.tb + d.tb_off;
     uint8_t *__restrict__ ta = qa + (a.pwm ? 4ull : 1ull) * cap;
-    const uint8_t *__restrict__ ops = a.tb + d.tb_off + (a.pwm ? 5ull : 2ull) * cap;
+    const uint8_t *__restrict__ ops = a.tags + d.tag_off;
     uint32_t *__restrict__ numbered = reinterpret_cast<uint32_t *>(qa);    // PWM: column numbers instead of query residues
     const uint32_t len = res.aln_len - (a.pwm ? 0u : 1u);
     // Position j reads ops[len - 1 - j] and needs the number of moves in x / y among positions 0..j: lane l takes position
-    // j0 + l, so tags, residues and both strings move in coalesced lines, the prefix counts come from two ballots, and four
+    // j0 + l, so tags, residues and both strings move in coalesced lines, the prefix counts come from two ballots, and two
     // such groups are in flight at once -- the loads of a group do not depend on the group before (a lane-contiguous split
     // was one dependent byte load per position: 2 x 35 round trips per pair).
     uint32_t base_y = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.start_y);
     uint32_t base_x = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.start_x);
-    for (uint32_t j0 = 0; j0 < len; j0 += 256u) {
-        uint32_t tag[4], px[4], py[4];
+    for (uint32_t j0 = 0; j0 < len; j0 += 64u * G) {
+        uint32_t tag[G], px[G], py[G];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < G; ++u) {
             const uint32_t j = j0 + 64u * u + (uint32_t)lane;
             tag[u] = (j < len) ? (uint32_t)ops[len - 1 - j] : 3u;      // 3: beyond the end, moves nothing
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < G; ++u) {
             const bool fx = (tag[u] != 2u) && (tag[u] != 3u), fy = (tag[u] != 1u) && (tag[u] != 3u);
             const uint64_t bx = __ballot(fx), by = __ballot(fy);
             px[u] = base_x + __builtin_amdgcn_mbcnt_hi((uint32_t)(bx >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bx, 0u)) + (fx ? 1u : 0u);
             py[u] = base_y + __builtin_amdgcn_mbcnt_hi((uint32_t)(by >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)by, 0u)) + (fy ? 1u : 0u);
             base_x += (uint32_t)__popcll(bx); base_y += (uint32_t)__popcll(by);
         }
-        uint32_t qv[4], tv[4];
+        uint32_t qv[G], tv[G];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                                   // the cell this step left: (py, px)
+        for (int u = 0; u < G; ++u) {                                   // the cell this step left: (py, px)
             qv[u] = (tag[u] == 2u || tag[u] == 3u) ? (uint32_t)a.blank : (a.pwm ? px[u] : (uint32_t)q[px[u] - 1]);
             tv[u] = (tag[u] == 1u || tag[u] == 3u) ? (uint32_t)a.blank : (uint32_t)t[py[u] - 1];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < G; ++u) {
             const uint32_t j = j0 + 64u * u + (uint32_t)lane;
             if (j < len) {
                 if (a.pwm) numbered[j] = (tag[u] == 2u) ? 0u : px[u];  // pwm/mod.rs:86-101
@@ -1446,6 +1486,11 @@ extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_seri
 #undef ALN_SINGLE4
 #undef ALN_SINGLE
 #undef ALN_SINGLE_LAUNCH
+}
+extern "C" void aln_launch_validate(const uint8_t *seqs, PairDesc *descs, uint32_t n_pairs, uint32_t rows, uint32_t cols, int pwm,
+                                    hipStream_t s)
+{
+    if (n_pairs) hipLaunchKernelGGL(aln_validate_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, s, seqs, descs, n_pairs, rows, cols, pwm ? 1u : 0u);
 }
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s)
 {

@@ -659,6 +659,104 @@ def test_c5_full_batch_against_oracle_digest(blosum62):
         if h.digest() != g["digests"][k].tobytes():
             bad.append(k)
     assert not bad, "blocks with a different digest: %s" % bad[:10]
+    # the staged API (whole batch resident in HBM, what bench.py times) gives the same bytes as the pipelined call
+    from aligner_amd.batch import align_batch_staged
+    again = align_batch_staged(b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    assert (again.results == r).all()
+    for i in range(0, len(b), 1013):
+        assert all((x == y).all() for x, y in zip(again.aligned(i), got.aligned(i)))
+
+
+def _spoil(b, rng, n_bad=7):
+    """Copies of the batch's arrays with a few residue codes outside the matrix and a few empty sequences."""
+    seqs = b.seqs.copy()
+    q_len, t_len = b.q_len.copy(), b.t_len.copy()
+    idx = rng.choice(len(b), size=2 * n_bad, replace=False)
+    for j, i in enumerate(idx[:n_bad]):
+        off = int(b.q_off[i] if j % 2 else b.t_off[i])
+        ln = int(b.q_len[i] if j % 2 else b.t_len[i])
+        seqs[off + int(rng.integers(0, ln))] = 24 + j          # outside the 24 x 24 matrix
+    for j, i in enumerate(idx[n_bad:]):
+        if j % 2:
+            q_len[i] = 0
+        else:
+            t_len[i] = 0
+    return PairBatch(seqs, b.q_off, q_len, b.t_off, t_len)
+
+
+def test_pipelined_batch_call_chunks_layouts_and_bad_pairs(orc, blosum62, monkeypatch):
+    """aln_align_batch is a pipeline over chunks of the caller's pair order (aln_host.hip).  Forced into ~15 chunks of a small
+    batch (ALN_CHUNK_CELLS): every summary and both strings against the oracle for (a) the documented cumulative tb layout
+    (copied back as one span per chunk), (b) a foreign layout (reversed, with gaps: staged and scattered per string),
+    (c) sequences scattered over a sparse buffer (gathered into staging), (d) pairs the reference panics on (codes outside the
+    matrix are found by the device-side validation; empty sequences on the host) spread over the chunks."""
+    rng = np.random.default_rng(99)
+    b = workloads.c5_batch(n_pairs=640, lo=20, hi=520)
+    monkeypatch.setenv("ALN_CHUNK_CELLS", str(b.cells // 15))
+    ref = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    # (b) reversed offsets with gaps of 5 bytes
+    cap = 2 * (b.q_len + b.t_len + np.uint64(2)) + np.uint64(5)
+    off = np.zeros(len(b), dtype=np.uint64)
+    off[::-1][1:] = np.cumsum(cap[::-1])[:-1]
+    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62, tb_off=off)
+    assert (got.results == ref.results).all()
+    # (c) the same pairs, every sequence at a far-away offset of a sparse buffer
+    gap = 9000
+    big = np.full(2 * len(b) * gap + 16, 77, dtype=np.uint8)
+    q_off = (np.arange(len(b), dtype=np.uint64) * 2 + 1) * gap
+    t_off = (np.arange(len(b), dtype=np.uint64) * 2) * gap + 13
+    for i in range(len(b)):
+        big[int(q_off[i]):int(q_off[i] + b.q_len[i])] = b.query(i)
+        big[int(t_off[i]):int(t_off[i] + b.t_len[i])] = b.target(i)
+    sparse = PairBatch(big, q_off, b.q_len, t_off, b.t_len)
+    got = align_batch(sparse, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    assert (got.results == ref.results).all()
+    for i in range(0, len(b), 7):
+        assert all((x == y).all() for x, y in zip(got.aligned(i), ref.aligned(i)))
+    # (d) bad pairs in several chunks, other semantics through the same pipeline
+    bad = _spoil(b, rng)
+    got = _check_batch(orc, bad, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    assert sorted(set(got.results["status"].tolist())) == [0, _ffi.ERR_EMPTY_SEQUENCE, _ffi.ERR_CODE_OUT_OF_RANGE]
+    _check_batch(orc, bad, _ffi.CORE_GLOBAL, 11, 2, blosum62)
+    _check_batch(orc, b, _ffi.LEGACY_LOCAL, 11, 11, blosum62)
+    _check_batch(orc, b, _ffi.CORE_LOCAL, 11.5, 2.25, blosum62 * 0.5)           # f64 kernels
+    # one chunk again: the same answers
+    monkeypatch.delenv("ALN_CHUNK_CELLS")
+    got = _check_batch(orc, bad, _ffi.CORE_LOCAL, 11, 2, blosum62)
+
+
+def test_concurrent_callers_share_the_slot_pool(orc, blosum62):
+    """Ten host threads call the library at once (statistics/mod.rs:255-286 runs ten aligner threads): the context's slots are
+    leased per call, results equal the serial ones."""
+    import threading
+    rng = np.random.default_rng(5)
+    batches = [workloads.c5_batch(n_pairs=40 + 3 * j, lo=20 + j, hi=300) for j in range(10)]
+    pairs = [(rng.integers(0, 20, 200 + 10 * j).astype(np.uint8), rng.integers(0, 20, 150 + 7 * j).astype(np.uint8)) for j in range(10)]
+    serial_b = [align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62) for b in batches]
+    serial_p = [runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, blosum62) for q, t in pairs]
+    out_b, out_p, errs = [None] * 10, [None] * 10, []
+
+    def work(j):
+        try:
+            for _ in range(3):
+                out_b[j] = align_batch(batches[j], _ffi.CORE_LOCAL, 11, 2, blosum62)
+                out_p[j] = runtime.align_pair(_ffi.CORE_LOCAL, pairs[j][0], pairs[j][1], 11, 2, blosum62)
+        except Exception as e:            # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(j,)) for j in range(10)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for j in range(10):
+        assert (out_b[j].results == serial_b[j].results).all(), j
+        for i in range(len(batches[j])):          # (bytes of tb past aln_len are unspecified)
+            assert all((x == y).all() for x, y in zip(out_b[j].aligned(i), serial_b[j].aligned(i))), (j, i)
+        a, b_ = out_p[j], serial_p[j]
+        assert (a[0].score, a[0].end_y, a[0].end_x, a[0].aln_len) == (b_[0].score, b_[0].end_y, b_[0].end_x, b_[0].aln_len)
+        assert a[1].tolist() == b_[1].tolist() and a[2].tolist() == b_[2].tolist()
+    q, t = pairs[0]
+    want = orc.align(orc.CORE_LOCAL, q, t, 11, 2, blosum62)
+    assert serial_p[0][0].score == want["score"] and serial_p[0][1].tolist() == want["qa"].tolist()
 
 
 def test_c3_full_batch_matches_oracle(orc):
