@@ -8,7 +8,9 @@ Workload (BASELINE.json configs[4], "C5"): 100 000 protein pairs, both lengths i
 core local semantics (SimpleLocalAligner), BLOSUM62, del 11 / ext 2.  The batch is fixed; with N > 1 the pairs are
 sharded over the ranks by balanced cells (LPT), so scaling is STRONG (total work fixed), as north_star asks
 ("scaling at 8 GPUs on a 100k-pair batch").  `--pairs` shrinks the batch for quick runs.
-At N = 1 the line also carries the single-pair configuration (configs[3], 10k x 10k) as "single_pair".
+At N = 1 the line also carries "end_to_end" (the same batch through aln_align_batch: host buffers in, host buffers out),
+the single-pair configuration (configs[3], 10k x 10k) as "single_pair", configs[1] and [2] as "configs", and the CPU oracle
+timed on a bounded sample ("cpu_baseline", all cores and one core; its results also check the GPU's on that sample).
 
 Launch: `python bench.py` (N=1) or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
@@ -31,9 +33,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s me
 ALG_BYTES_PER_CELL = 0.25      # one 2-bit direction per cell is the only per-cell datum that must leave the chip
 
 
-def cpu_baseline(batch, S, target_seconds=15.0):
+def cpu_baseline(batch, S, gpu_results, target_seconds=12.0):
     """Times the CPU oracle (the reference's algorithm and memory behaviour, oracle/aligner_oracle.c) on a bounded
-    sample of the SAME workload, all host cores, static pair partitioning (statistics/mod.rs:255-286 style)."""
+    sample of the SAME workload: all host cores with static pair partitioning (statistics/mod.rs:255-286 style) and ONE core
+    (the reference is single-threaded per pair).  The sample's oracle results also check the GPU's summaries of those pairs."""
     import oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, min(cores, 64))
@@ -42,15 +45,111 @@ def cpu_baseline(batch, S, target_seconds=15.0):
     for _ in range(3):
         sample = batch.select(range(n))
         t0 = time.perf_counter()
-        oracle.align_batch(oracle.CORE_LOCAL, sample.seqs, sample.q_off, sample.q_len, sample.t_off, sample.t_len, 11,
-                           2, S, threads)
+        ref, _, _ = oracle.align_batch(oracle.CORE_LOCAL, sample.seqs, sample.q_off, sample.q_len, sample.t_off, sample.t_len, 11,
+                                       2, S, threads)
         dt = time.perf_counter() - t0
         if dt >= 0.6 * target_seconds or n == len(batch):
             break
         n = int(min(len(batch), max(n + 1, n * target_seconds / max(dt, 1e-3))))
+    mismatches = 0
+    for i in range(n):
+        r, g = ref[i], gpu_results[i]
+        mismatches += (g["status"], g["score"], g["end_y"], g["end_x"], g["start_y"], g["start_x"], g["aln_len"]) != \
+                      (r.status, r.score, r.end_y, r.end_x, r.start_y, r.start_x, r.aln_len)
+    n1 = max(1, min(n, 24))
+    one = batch.select(range(n1))
+    t0 = time.perf_counter()
+    oracle.align_batch(oracle.CORE_LOCAL, one.seqs, one.q_off, one.q_len, one.t_off, one.t_len, 11, 2, S, 1)
+    dt1 = time.perf_counter() - t0
     return {"value": round(sample.cells / dt / 1e9, 4), "unit": "GCUPS", "cores": threads, "kind": "port",
             "sample": "first %d of the batch's pairs (%.3g cells), fill+argmax+traceback, %.1f s wall" % (
-                n, sample.cells, dt)}
+                n, sample.cells, dt),
+            "one_core": {"value": round(one.cells / dt1 / 1e9, 5), "unit": "GCUPS", "cores": 1,
+                         "sample": "first %d pairs (%.3g cells), %.1f s" % (n1, one.cells, dt1)},
+            "parity_vs_gpu": {"pairs_compared": n, "mismatches": int(mismatches)}}
+
+
+def end_to_end(batch, S, local_rank, calls=3):
+    """The same job through aln_align_batch: HOST buffers in (residue codes, offsets), HOST buffers out (summaries and both
+    aligned strings of every pair) -- what a caller of the C ABI sees.  The pool is warm after the first call."""
+    from aligner_amd import _ffi, runtime
+    from aligner_amd.batch import RESULT_DTYPE
+    lib = _ffi.load()
+    p, keep = runtime.make_params(_ffi.CORE_LOCAL, 11, 2, S, outputs=_ffi.OUT_SCORE | _ffi.OUT_TRACEBACK)
+    res = np.zeros(len(batch), dtype=RESULT_DTYPE)
+    tb_off, total = batch.tb_layout()
+    tb = np.zeros(max(total, 1), dtype=np.uint8)
+    ctx = runtime.context(local_rank)
+    times = []
+    for i in range(calls + 1):
+        t0 = time.perf_counter()
+        st = lib.aln_align_batch(ctx, C.byref(p), batch.seqs.ctypes.data, batch.q_off.ctypes.data, batch.q_len.ctypes.data,
+                                 batch.t_off.ctypes.data, batch.t_len.ctypes.data, len(batch), res.ctypes.data, tb.ctypes.data,
+                                 tb_off.ctypes.data)
+        times.append(time.perf_counter() - t0)
+        runtime.raise_for_status(st, "aln_align_batch")
+    warm = sorted(times[1:])
+    med = warm[len(warm) // 2]
+    return {"what": "aln_align_batch: host buffers in, summaries + both aligned strings of every pair out (chunked pipeline)",
+            "ms": round(med * 1e3, 3), "gcups": round(batch.cells / med / 1e9, 2), "calls": calls,
+            "first_call_ms_cold_pool": round(times[0] * 1e3, 2), "host_bytes_in": int(len(batch.seqs)), "host_bytes_out": int(total),
+            "pairs_ok": int((res["status"] == 0).sum())}, res
+
+
+def small_configs(S, local_rank, stream, torch):
+    """BASELINE.json configs[1] (C2) and configs[2] (C3), plus the PWM window batch of SURVEY 8f-1: recorded beside the
+    headline so that every quoted figure has a line in the driver's record."""
+    from aligner_amd import _ffi, runtime, workloads
+    from aligner_amd.batch import PairBatch, StagedBatch
+    from aligner_amd.matrices import nucleotide_matrix
+    out = {}
+    outs = _ffi.OUT_SCORE | _ffi.OUT_TRACEBACK
+
+    def staged(b, sem, d, e, M, reps):
+        sb = StagedBatch(b, sem, d, e, M, device=local_rank, outputs=outs)
+        with torch.cuda.stream(stream):
+            sb.run(stream.cuda_stream)
+        torch.cuda.synchronize()
+        sb.enable_timing(True)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(reps):
+                sb.run(stream.cuda_stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        tm = sb.timing()
+        r = sb.fetch(want_traceback=False).results
+        dirs = sb.direction_bytes
+        sb.close()
+        return dt, tm, r, dirs
+
+    # C2: one 1k x 1k protein pair, core local 11/2
+    q, t = workloads.c2_pair(homolog=False)
+    one = PairBatch.from_pairs([(q, t)])
+    dt, tm, r, _ = staged(one, _ffi.CORE_LOCAL, 11, 2, S, 50)
+    runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, S, device=local_rank)
+    walls = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, S, device=local_rank)
+        walls.append(time.perf_counter() - t0)
+    walls.sort()
+    out["C2"] = {"workload": "one 1000 x 1000 protein pair, core local, BLOSUM62, 11/2",
+                 "device_ms": round(tm["fill_ms"] + tm["traceback_ms"], 4), "fill_ms": round(tm["fill_ms"], 4),
+                 "traceback_ms": round(tm["traceback_ms"], 4), "kernel_launches_fill": tm["fill_launches"],
+                 "staged_run_ms": round(dt * 1e3, 4), "gcups_staged": round(one.cells / dt / 1e9, 3),
+                 "aln_align_pair_wall_ms_median": round(walls[len(walls) // 2] * 1e3, 4),
+                 "aln_align_pair_wall_ms_min": round(walls[0] * 1e3, 4), "score": float(r[0]["score"]), "status": int(r[0]["status"])}
+    # C3: 10 000 nucleotide read pairs 150 x 150, core global, +5/-4, 10/1
+    b3 = workloads.c3_batch(10000)
+    dt, tm, r, dirs = staged(b3, _ffi.CORE_GLOBAL, 10, 1, nucleotide_matrix(), 50)
+    alg = 0.25 * b3.cells + float((b3.q_len + b3.t_len).sum()) + 48.0 * len(b3)
+    out["C3"] = {"workload": "10000 nucleotide read pairs 150 x 150, core global, +5/-4, del 10 / ext 1",
+                 "ms": round(dt * 1e3, 4), "gcups": round(b3.cells / dt / 1e9, 2), "fill_ms": round(tm["fill_ms"], 4),
+                 "traceback_ms": round(tm["traceback_ms"], 4), "fill_only_gcups": round(b3.cells / tm["fill_ms"] / 1e6, 2),
+                 "alg_bytes_per_launch": alg, "alg_hbm_gbs": round(alg / (tm["fill_ms"] / 1e3) / 1e9, 2),
+                 "direction_bytes_stored": dirs, "pairs_ok": int((r["status"] == 0).sum())}
+    return out
 
 
 def main():
@@ -61,6 +160,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=100000, help="size of the C5 batch (default: the full 100 000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-small-configs", action="store_true")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="world size 1 only: run the RCCL process group and the summary gather of the N > 1 path anyway")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
@@ -160,17 +261,18 @@ def main():
         fill_s = timing["fill_ms"] / 1e3
         alg_bytes = ALG_BYTES_PER_CELL * batch.cells + float((batch.q_len + batch.t_len).sum()) + 48.0 * len(batch)
         achieved = alg_bytes / fill_s / 1e9
-        traffic = valu_insts = None
+        traffic = valu_insts = lds_ratio = None
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
             key = "c5_%d_n%d" % (args.pairs, world)
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             valu_insts = tj.get(key, {}).get("valu_wave_insts_per_launch")
+            lds_ratio = tj.get(key, {}).get("lds_bank_conflict_ratio")
         except Exception:
-            traffic = valu_insts = None
+            traffic = valu_insts = lds_ratio = None
         line = {
-            "metric": "GCUPS (DP cell updates/s), fill + traceback, bit-exact vs CPU ref",
+            "metric": "GCUPS (DP cell updates/s), fill + traceback, inputs resident in HBM",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
@@ -185,17 +287,33 @@ def main():
                          "traceback_ms": round(timing["traceback_ms"], 4),
                          "fill_only_gcups_rank0": round(batch.cells / fill_s / 1e9, 3),
                          "direction_bytes_stored": sb.direction_bytes,
+                         "traffic_over_alg": (round(traffic / alg_bytes, 3) if traffic else None),
+                         "lds_bank_conflict_ratio": lds_ratio,     # SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (PMC pass)
+                         # HBM is not what binds this integer DP; VALU issue is.  valu_frac: SURVEY's accounting,
+                         # 16 lane-ops per cell against 78.6 T lane-ops/s (every instruction at the 2-cycle rate).
+                         "binding_roof": "valu_issue",
                          "valu_frac": round(batch.cells / fill_s * 16 / 78.6e12, 5),
-                         # the binding roof: VALU issue.  PMC-counted wave instructions per launch / kernel time over the
-                         # chip's 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 int32 instruction
-                         "valu_issue_frac": (round(valu_insts / fill_s / 614.4e9, 4) if valu_insts else None)},
-            # never `value`: the same job when the boundary hands over HOST buffers (one staging + one step + one fetch)
+                         # valu_issue_frac: PMC-counted wave instructions per launch / kernel time against the roof of the
+                         # kernel's own instruction mix -- 10 of a cell's 11 VALU instructions are in gfx950's 4-cycle class
+                         # (measured per instruction: profiles/r02_valu_rate.txt): 1024 SIMDs x 2.4 GHz / 4 = 614.4 G/s.
+                         # valu_fullrate_frac: the same count against the 2-cycle roof (1228.8 G/s).
+                         "valu_issue_frac": (round(valu_insts / fill_s / 614.4e9, 4) if valu_insts else None),
+                         "valu_fullrate_frac": (round(valu_insts / fill_s / 1228.8e9, 4) if valu_insts else None)},
+            # never `value`: the staged API's own hand-over costs (aln_batch_create = allocations + H2D; aln_batch_fetch = D2H of
+            # every summary and string), serial around one step.  The pipelined host-buffer call is "end_to_end" below.
             "pcie_inclusive": {"stage_ms": round(t_stage * 1e3, 2), "fetch_ms": round(t_fetch * 1e3, 2),
                                "gcups_rank0": round(batch.cells / (t_stage + elapsed / args.steps + t_fetch) / 1e9, 2)},
         }
 
-    # ---- N = 1 extras: the single-pair configuration and the CPU baseline
+    # ---- N = 1 extras: the host-buffer call, the single-pair configuration, the small configurations, the CPU baseline
+    sb.close()
     if rank == 0 and world == 1:
+        e2e_res = None
+        if not args.no_end_to_end:
+            line["end_to_end"], e2e_res = end_to_end(batch, S, local_rank)
+            assert (e2e_res == res).all(), "the pipelined call and the staged batch disagree"
+        if not args.no_small_configs:
+            line["configs"] = small_configs(S, local_rank, stream, torch)
         if not args.no_single_pair:
             q, t = workloads.c4_pair(homolog=False)
             one = PairBatch.from_pairs([(q, t)])
@@ -220,10 +338,9 @@ def main():
                                    "score": float(r1["score"]), "status": int(r1["status"])}
             sp.close()
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(batch, S)
+            line["cpu_baseline"] = cpu_baseline(batch, S, res)
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    sb.close()
     if use_dist:
         dist.destroy_process_group()
 
