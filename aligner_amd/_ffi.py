@@ -30,8 +30,8 @@ OUT_SCORE, OUT_TRACEBACK, OUT_DIRECTIONS, OUT_H_MATRIX = 1, 2, 4, 8
 
 # every symbol include/aligner_hip.h declares
 EXPORTS = [
-    "aln_create", "aln_destroy", "aln_last_error", "aln_abi_version", "aln_device_info", "aln_align_pair",
-    "aln_align_batch", "aln_batch_create", "aln_batch_run", "aln_batch_sync", "aln_batch_fetch",
+    "aln_create", "aln_create_multi", "aln_device_count", "aln_destroy", "aln_last_error", "aln_abi_version", "aln_device_info", "aln_align_pair",
+    "aln_align_batch", "aln_plan_chunks", "aln_batch_create", "aln_batch_run", "aln_batch_sync", "aln_batch_fetch",
     "aln_batch_destroy", "aln_batch_cells", "aln_batch_size", "aln_batch_results_device",
     "aln_batch_direction_bytes", "aln_batch_timing", "aln_batch_enable_timing",
 ]
@@ -69,6 +69,10 @@ def load():
     vp, i, u64p = C.c_void_p, C.c_int, C.c_void_p
     lib.aln_create.restype = vp
     lib.aln_create.argtypes = [i, C.POINTER(C.c_int)]
+    lib.aln_create_multi.restype = vp
+    lib.aln_create_multi.argtypes = [i, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.aln_device_count.restype = i
+    lib.aln_device_count.argtypes = [vp]
     lib.aln_destroy.restype = None
     lib.aln_destroy.argtypes = [vp]
     lib.aln_last_error.restype = C.c_char_p
@@ -81,6 +85,8 @@ def load():
                                    vp, vp, vp]
     lib.aln_align_batch.restype = i
     lib.aln_align_batch.argtypes = [vp, C.POINTER(Params), vp, u64p, u64p, u64p, u64p, C.c_size_t, vp, vp, u64p]
+    lib.aln_plan_chunks.restype = C.c_size_t
+    lib.aln_plan_chunks.argtypes = [C.POINTER(Params), u64p, u64p, C.c_size_t, i, u64p, u64p, C.c_size_t]
     lib.aln_batch_create.restype = vp
     lib.aln_batch_create.argtypes = [vp, C.POINTER(Params), vp, u64p, u64p, u64p, u64p, C.c_size_t,
                                      C.POINTER(C.c_int)]

@@ -156,12 +156,13 @@ class BatchResult:
 
 
 def align_batch(batch, semantics, del_, ext, matrix, device=None, want_traceback=True, tb_off=None, outputs=None, blank=98,
-                **kw):
+                devices=None, **kw):
     """Blocking batch call through aln_align_batch: host buffers in, host buffers out.  The library cuts the batch into
     chunks and overlaps upload, fill, traceback and download (aln_host.hip).  Returns a BatchResult.
 
     tb_off: optional caller-chosen offsets of the aligned strings (default: the documented cumulative layout, which the
-    library copies back without a per-pair scatter)."""
+    library copies back without a per-pair scatter).  devices: a list of GPU ids of this process to shard the chunks over
+    (runtime.context_multi); default: the one device of `device`."""
     lib = _ffi.load()
     outs = outputs if outputs is not None else _ffi.OUT_SCORE | (_ffi.OUT_TRACEBACK if want_traceback else 0)
     p, keep = runtime.make_params(semantics, del_, ext, matrix, outputs=outs, blank=blank, **kw)
@@ -176,7 +177,8 @@ def align_batch(batch, semantics, del_, ext, matrix, device=None, want_traceback
             cap = 2 * (batch.q_len + batch.t_len + np.uint64(2))
             total = int((tb_off + cap).max()) if n else 0
         tb = np.zeros(max(total, 1), dtype=np.uint8)
-    st = lib.aln_align_batch(runtime.context(device), C.byref(p), batch.seqs.ctypes.data, batch.q_off.ctypes.data,
+    ctx = runtime.context_multi(devices) if devices is not None else runtime.context(device)
+    st = lib.aln_align_batch(ctx, C.byref(p), batch.seqs.ctypes.data, batch.q_off.ctypes.data,
                              batch.q_len.ctypes.data, batch.t_off.ctypes.data, batch.t_len.ctypes.data, n,
                              res.ctypes.data, tb.ctypes.data if want_traceback else None,
                              tb_off.ctypes.data if want_traceback else None)

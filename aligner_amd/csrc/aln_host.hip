@@ -130,7 +130,8 @@ struct Slot {
     bool walked_clean = false;
 };
 
-struct aln_ctx {
+// one GPU of a context: its properties and its slot pool
+struct DevCtx {
     int device = 0;
     int cus = 0;
     size_t hbm = 0;
@@ -139,6 +140,14 @@ struct aln_ctx {
     std::condition_variable cv;
     Slot *slots[ALN_POOL_SLOTS] = {nullptr};
     bool busy[ALN_POOL_SLOTS] = {false};
+};
+
+// A context spans one or more GPUs of this process (aln_create: one; aln_create_multi: a list).  Single calls go to the
+// devices in turn; a batch call is cut into chunks that the devices take from a common queue.
+struct aln_ctx {
+    std::vector<DevCtx *> devs;
+    std::atomic<uint32_t> turn{0};
+    DevCtx *next_device() { return devs[turn.fetch_add(1, std::memory_order_relaxed) % devs.size()]; }
 };
 
 static int slot_init(Slot &s)
@@ -165,7 +174,7 @@ static void slot_destroy(Slot *s)
 }
 
 // takes between 1 and `want` free pool slots (blocks while none is free); concurrent callers share the pool
-static int pool_lease(aln_ctx *ctx, int want, Slot **out)
+static int pool_lease(DevCtx *ctx, int want, Slot **out)
 {
     std::unique_lock<std::mutex> lk(ctx->mu);
     int got = 0;
@@ -180,7 +189,7 @@ static int pool_lease(aln_ctx *ctx, int want, Slot **out)
         ctx->cv.wait(lk);
     }
 }
-static void pool_release(aln_ctx *ctx, Slot **slots, int n)
+static void pool_release(DevCtx *ctx, Slot **slots, int n)
 {
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -194,7 +203,7 @@ static void pool_release(aln_ctx *ctx, Slot **slots, int n)
 extern "C" const char *aln_last_error(void) { return g_err.c_str(); }
 extern "C" int aln_abi_version(void) { return ALN_ABI_VERSION; }
 
-extern "C" aln_ctx *aln_create(int device_id, int *status)
+extern "C" aln_ctx *aln_create_multi(int n_devices, const int *device_ids, int *status)
 {
     int st = ALN_OK;
     aln_ctx *c = nullptr;
@@ -203,39 +212,60 @@ extern "C" aln_ctx *aln_create(int device_id, int *status)
     if (e != hipSuccess || ndev <= 0) {
         g_err = e != hipSuccess ? std::string("hipGetDeviceCount: ") + hipGetErrorString(e) : "no HIP device visible";
         st = ALN_ERR_DEVICE;
-    } else if (device_id < 0 || device_id >= ndev) {
-        g_err = "device id out of range";
+    } else if (n_devices < 0 || n_devices > 64 || (n_devices > 0 && !device_ids)) {
+        g_err = "bad device list";
         st = ALN_ERR_INVALID_ARGUMENT;
     } else {
-        hipDeviceProp_t prop;
-        if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
-            st = fail(e, "hipSetDevice/hipGetDeviceProperties");
-        } else {
-            c = new aln_ctx();
-            c->device = device_id;
-            c->cus = prop.multiProcessorCount;
-            c->hbm = prop.totalGlobalMem;
-            snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+        std::vector<int> ids;
+        if (n_devices == 0) for (int i = 0; i < ndev; ++i) ids.push_back(i);          // every visible device
+        else ids.assign(device_ids, device_ids + n_devices);
+        c = new aln_ctx();
+        for (int id : ids) {
+            if (id < 0 || id >= ndev) { g_err = "device id out of range"; st = ALN_ERR_INVALID_ARGUMENT; break; }
+            hipDeviceProp_t prop;
+            if ((e = hipSetDevice(id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, id)) != hipSuccess) {
+                st = fail(e, "hipSetDevice/hipGetDeviceProperties");
+                break;
+            }
+            DevCtx *d = new DevCtx();
+            d->device = id;
+            d->cus = prop.multiProcessorCount;
+            d->hbm = prop.totalGlobalMem;
+            snprintf(d->name, sizeof d->name, "%s (%s)", prop.name, prop.gcnArchName);
+            c->devs.push_back(d);
+        }
+        if (st != ALN_OK) {
+            for (DevCtx *d : c->devs) delete d;
+            delete c;
+            c = nullptr;
         }
     }
     if (status) *status = st;
     return c;
 }
 
+extern "C" aln_ctx *aln_create(int device_id, int *status) { return aln_create_multi(1, &device_id, status); }
+
 extern "C" void aln_destroy(aln_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    for (Slot *s : ctx->slots) slot_destroy(s);
+    for (DevCtx *d : ctx->devs) {
+        (void)hipSetDevice(d->device);
+        for (Slot *s : d->slots) slot_destroy(s);
+        delete d;
+    }
     delete ctx;
 }
+
+extern "C" int aln_device_count(const aln_ctx *ctx) { return ctx ? (int)ctx->devs.size() : 0; }
 
 extern "C" int aln_device_info(aln_ctx *ctx, int *cus, size_t *hbm, char *name, size_t cap)
 {
     if (!ctx) return ALN_ERR_INVALID_ARGUMENT;
-    if (cus) *cus = ctx->cus;
-    if (hbm) *hbm = ctx->hbm;
-    if (name && cap) { strncpy(name, ctx->name, cap - 1); name[cap - 1] = 0; }
+    const DevCtx *d = ctx->devs[0];
+    if (cus) *cus = d->cus;
+    if (hbm) *hbm = d->hbm;
+    if (name && cap) { strncpy(name, d->name, cap - 1); name[cap - 1] = 0; }
     return ALN_OK;
 }
 
@@ -336,7 +366,7 @@ struct Chunk {
     uint64_t seq_lo = 0, seq_span = 0;
 };
 
-static int chunk_plan(const aln_ctx *ctx, const Call &c, const uint64_t *q_off, const uint64_t *q_len, const uint64_t *t_off,
+static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, const uint64_t *q_len, const uint64_t *t_off,
                       const uint64_t *t_len, size_t first, size_t n, bool allow_overlap, Chunk &k)
 {
     k.first = first; k.n = n;
@@ -593,7 +623,7 @@ static int slot_upload(Slot &s, const Call &c, const Chunk &k, const uint8_t *se
 // All kernels of one chunk, asynchronous on `st`: validation of the residue codes, fill (+ exact re-fills), traceback.
 // ev (optional): three timing events (fill start, fill end, traceback end).
 // fill_after (optional): an event the fill has to wait for (pipelined calls: the fill of the chunk two before, see below).
-static int slot_launch(aln_ctx *ctx, Slot &s, const Call &c, const Chunk &k, hipStream_t st, hipEvent_t *ev, uint32_t *fill_launches,
+static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipStream_t st, hipEvent_t *ev, uint32_t *fill_launches,
                        hipEvent_t fill_after = nullptr)
 {
     (void)ctx;
@@ -742,12 +772,14 @@ static int slot_download(Slot &s, const Call &c, const Chunk &k, hipStream_t st,
 // ~3 ms on its wave whatever else runs) do not outlast it by much.  ALN_CHUNK_CELLS overrides.
 // Measured (profiles/r02_e2e_chunking.txt): C5 100 000 pairs (47.3 ms resident): 30 chunks 60 ms, 16 chunks 54 ms, 8 chunks 52 ms;
 // 25 000 pairs: 6 chunks 18.2 ms, 2-4 chunks 16.6-17.1, one chunk 21.1; 12 500 pairs: 7 chunks 15.6 ms, 3 chunks 9.7, one 10.7.
-static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_len, size_t n, std::vector<std::pair<size_t, size_t>> &out)
+static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_len, size_t n, size_t ndev,
+                        std::vector<std::pair<size_t, size_t>> &out)
 {
     out.clear();
     double total = 0;
     for (size_t i = 0; i < n; ++i) total += (double)(c.pwm ? c.cols : q_len[i]) * (double)t_len[i];
-    double target = std::min(1.6e10, std::max(5.0e9, total / 4.0));
+    // (several devices: the same bounds per device -- each takes about three chunks or more from the common queue)
+    double target = std::min(1.6e10, std::max(5.0e9, total / (4.0 * (double)ndev)));
     if (const char *e = getenv("ALN_CHUNK_CELLS")) target = std::max(1.0, atof(e));
     if (total <= 1.5 * target) { out.emplace_back(0, n); return; }
     size_t first = 0;
@@ -763,6 +795,131 @@ static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_
     }
 }
 
+// The chunking aln_align_batch would use for these lengths on a context of n_devices GPUs: pure host arithmetic (no device is
+// touched), exported so that the sharding can be inspected and tested anywhere.  Returns the number of chunks; writes up to
+// `cap` (first pair, pair count) entries.
+extern "C" size_t aln_plan_chunks(const aln_params *params, const uint64_t *q_len, const uint64_t *t_len, size_t n_pairs,
+                                  int n_devices, uint64_t *first, uint64_t *count, size_t cap)
+{
+    if (!params || (n_pairs && (!q_len || !t_len)) || n_devices < 1) return 0;
+    Call c;
+    c.pwm = params->semantics == ALN_PWM_LOCAL;
+    c.cols = params->cols;
+    std::vector<std::pair<size_t, size_t>> ranges;
+    if (n_pairs) make_chunks(c, q_len, t_len, n_pairs, (size_t)n_devices, ranges);
+    for (size_t i = 0; i < ranges.size() && i < cap; ++i) {
+        if (first) first[i] = ranges[i].first;
+        if (count) count[i] = ranges[i].second;
+    }
+    return ranges.size();
+}
+
+// everything a pipelined call shares between its threads
+struct BatchJob {
+    const Call *c;
+    const uint8_t *seqs;
+    const uint64_t *q_off, *q_len, *t_off, *t_len;
+    aln_pair_result *results;
+    uint8_t *tb_buf;
+    const uint64_t *tb_off;
+    const std::vector<std::pair<size_t, size_t>> *ranges;
+    Need need;
+    std::atomic<size_t> next{0};       // the chunk queue: devices take the next range when they have a free slot
+    std::atomic<int> failed{0};
+    std::mutex mu;
+    int status = ALN_OK;
+    std::string err;
+    void fail_with(int st, const std::string &e)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (status == ALN_OK) { status = st; err = e; }
+        failed.store(1);
+    }
+};
+
+// One device's share of a pipelined call: this thread takes chunks from the job's queue, plans, uploads and launches them; a
+// second thread waits for each chunk's kernels and copies its results back; a slot is reused once its chunk has been fetched.
+static void device_pipeline(DevCtx *dev, BatchJob &job)
+{
+    if (hipSetDevice(dev->device) != hipSuccess) { job.fail_with(ALN_ERR_DEVICE, "hipSetDevice failed"); return; }
+    const Call &c = *job.c;
+    const size_t nc = job.ranges->size();
+    Slot *slots[ALN_POOL_SLOTS];
+    const int ns = pool_lease(dev, ALN_POOL_SLOTS, slots);
+    struct Release { DevCtx *c; Slot **s; int n; ~Release() { pool_release(c, s, n); } } rel{dev, slots, ns};
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::pair<size_t, int>> ready;      // (local chunk number, slot) launched, to be fetched, in order
+        std::vector<char> slot_free;
+        bool done_issuing = false;
+    } sh;
+    sh.slot_free.assign(ns, 1);
+    std::vector<Chunk> plans(ns);                      // the plan of the chunk each slot holds
+    size_t depth = 3;
+    if (const char *e = getenv("ALN_FILL_DEPTH")) depth = std::max(1, atoi(e));
+    std::thread fetcher([&] {
+        (void)hipSetDevice(dev->device);
+        for (;;) {
+            int si;
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv.wait(lk, [&] { return !sh.ready.empty() || sh.done_issuing; });
+                if (sh.ready.empty()) return;
+                si = sh.ready.front().second;
+                sh.ready.pop_front();
+            }
+            Slot &s = *slots[si];
+            const int e = slot_download(s, c, plans[si], s.stream, job.results, job.tb_buf, job.tb_off);
+            if (e != ALN_OK) job.fail_with(e, g_err);
+            {
+                std::lock_guard<std::mutex> lk(sh.mu);
+                sh.slot_free[si] = 1;
+            }
+            sh.cv.notify_all();
+        }
+    });
+    int st = ALN_OK;
+    for (size_t li = 0; st == ALN_OK && !job.failed.load(); ++li) {
+        const int si = (int)(li % (size_t)ns);
+        {   // the slot's previous chunk must have been fetched before its plan and buffers are reused
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv.wait(lk, [&] { return sh.slot_free[si] != 0; });
+        }
+        const size_t ci = job.next.fetch_add(1);
+        if (ci >= nc) break;
+        Chunk &k = plans[si];
+        k = Chunk();
+        // (walk waves beside the LAST chunk's own fill, as a staged batch has them, were measured: 53.7 ms against 52.0 without)
+        st = chunk_plan(dev, c, job.q_off, job.q_len, job.t_off, job.t_len, (*job.ranges)[ci].first, (*job.ranges)[ci].second, false, k);
+        if (st != ALN_OK) break;
+        Slot &s = *slots[si];
+        if ((st = slot_ensure(s, c, k, &job.need)) != ALN_OK) break;
+        if ((st = slot_upload(s, c, k, job.seqs, job.q_off, job.q_len, job.t_off, job.t_len, s.stream)) != ALN_OK) break;
+        // At most `depth` fills share the chip: chunk i's fill waits for the fill of chunk i - depth.  With every slot's fill
+        // started at once the chunks run in lockstep -- they share the chip equally, reach their tails together (a chunk's
+        // largest pairs take as long as the whole chunk), then all walk and copy while nothing fills.  Fewer at a time stay
+        // staggered: the oldest is in its tail while the younger ones fill the waves it leaves free (C5, 16 chunks: depth
+        // 1: 83 ms, 2: 53.7, 3: 52.6, 4 = every slot: 56.5).
+        hipEvent_t after = (li >= depth && ns > (int)depth) ? slots[(li - depth) % (size_t)ns]->ev_fill : nullptr;
+        if ((st = slot_launch(dev, s, c, k, s.stream, nullptr, nullptr, after)) != ALN_OK) break;
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.slot_free[si] = 0;
+            sh.ready.emplace_back(li, si);
+        }
+        sh.cv.notify_all();
+    }
+    if (st != ALN_OK) job.fail_with(st, g_err);
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);
+        sh.done_issuing = true;
+    }
+    sh.cv.notify_all();
+    fetcher.join();
+    for (int i = 0; i < ns; ++i) (void)hipStreamSynchronize(slots[i]->stream);
+}
+
 extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
                                const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
                                aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off)
@@ -772,18 +929,33 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
     int st = call_init(c, params, q_len, t_len, n_pairs, false);
     if (st != ALN_OK) return st;
     if (n_pairs == 0) return ALN_OK;
-    HIPCHK(hipSetDevice(ctx->device));
     std::vector<std::pair<size_t, size_t>> ranges;
-    make_chunks(c, q_len, t_len, n_pairs, ranges);
+    make_chunks(c, q_len, t_len, n_pairs, ctx->devs.size(), ranges);
     const size_t nc = ranges.size();
 
-    Slot *slots[ALN_POOL_SLOTS];
-    const int ns = pool_lease(ctx, (int)std::min<size_t>(nc, nc > 1 ? ALN_POOL_SLOTS : 1), slots);
-    struct Release { aln_ctx *c; Slot **s; int n; ~Release() { pool_release(c, s, n); } } rel{ctx, slots, ns};
+    if (nc == 1) {                                   // one chunk: everything on the caller's thread, on the next device in turn
+        DevCtx *dev = ctx->next_device();
+        HIPCHK(hipSetDevice(dev->device));
+        Slot *sl[1];
+        pool_lease(dev, 1, sl);
+        struct Release { DevCtx *c; Slot **s; ~Release() { pool_release(c, s, 1); } } rel{dev, sl};
+        Chunk k;
+        Slot &s = *sl[0];
+        if ((st = chunk_plan(dev, c, q_off, q_len, t_off, t_len, 0, n_pairs, true, k)) != ALN_OK) return st;
+        if ((st = slot_ensure(s, c, k)) != ALN_OK) return st;
+        if ((st = slot_upload(s, c, k, seqs, q_off, q_len, t_off, t_len, s.stream)) != ALN_OK) return st;
+        if ((st = slot_launch(dev, s, c, k, s.stream, nullptr, nullptr)) != ALN_OK) { (void)hipStreamSynchronize(s.stream); return st; }
+        return slot_download(s, c, k, s.stream, results, tb_buf, tb_off);
+    }
 
-    Need need;
-    if (nc > 1) {
+    BatchJob job;
+    job.c = &c; job.seqs = seqs; job.q_off = q_off; job.q_len = q_len; job.t_off = t_off; job.t_len = t_len;
+    job.results = results; job.tb_buf = tb_buf; job.tb_off = tb_off; job.ranges = &ranges;
+    {   // upper bounds over the chunks: every slot is sized once, before the pipeline runs
         const uint64_t sc = c.is_int ? 4 : 8;
+        int max_cus = 0;
+        for (const DevCtx *d : ctx->devs) max_cus = std::max(max_cus, d->cus);
+        Need &need = job.need;
         for (const auto &r : ranges) {
             uint64_t lo = ~0ull, hi = 0, sum = 0, dirs = 0, tb = 0, tags = 0, mlen = 1;
             for (size_t i = r.first; i < r.first + r.second; ++i) {
@@ -804,103 +976,22 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
             const uint64_t stride = (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull) +
                                     std::max<uint64_t>((mlen + 66 + 63) & ~63ull, (4 * ((mlen + 63) / 2 + 8) + 63) & ~63ull) +
                                     (c.fast ? ((uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 + (((mlen + 66) * 4 + 63) & ~63ull)) : 0);
-            need.scratch = std::max(need.scratch, (uint64_t)ctx->cus * 4 * 4 * stride);
+            need.scratch = std::max(need.scratch, (uint64_t)max_cus * 4 * 4 * stride);
         }
     }
-
-    if (nc == 1) {                                   // one chunk: everything on the caller's thread
-        Chunk k;
-        Slot &s = *slots[0];
-        if ((st = chunk_plan(ctx, c, q_off, q_len, t_off, t_len, 0, n_pairs, true, k)) != ALN_OK) return st;
-        if ((st = slot_ensure(s, c, k)) != ALN_OK) return st;
-        if ((st = slot_upload(s, c, k, seqs, q_off, q_len, t_off, t_len, s.stream)) != ALN_OK) return st;
-        if ((st = slot_launch(ctx, s, c, k, s.stream, nullptr, nullptr)) != ALN_OK) { (void)hipStreamSynchronize(s.stream); return st; }
-        return slot_download(s, c, k, s.stream, results, tb_buf, tb_off);
-    }
-
-    // ---- pipeline: this thread plans, uploads and launches chunk after chunk; a second thread waits for each chunk's
-    // kernels and copies its results back; a slot is reused once its previous chunk has been fetched.
-    struct Shared {
-        std::mutex mu;
-        std::condition_variable cv;
-        std::deque<size_t> ready;          // chunks launched, to be fetched, in order
-        std::vector<char> slot_free;
-        bool done_issuing = false;
-        int status = ALN_OK;
-        std::string err;
-    } sh;
-    sh.slot_free.assign(ns, 1);
-    std::vector<Chunk> chunks(nc);
-    size_t depth = 3;
-    if (const char *e = getenv("ALN_FILL_DEPTH")) depth = std::max(1, atoi(e));
-    const int dev = ctx->device;
-    std::thread fetcher([&] {
-        (void)hipSetDevice(dev);
-        for (;;) {
-            size_t ci;
-            {
-                std::unique_lock<std::mutex> lk(sh.mu);
-                sh.cv.wait(lk, [&] { return !sh.ready.empty() || sh.done_issuing; });
-                if (sh.ready.empty()) return;
-                ci = sh.ready.front();
-                sh.ready.pop_front();
-            }
-            const int si = (int)(ci % (size_t)ns);
-            Slot &s = *slots[si];
-            int e = slot_download(s, c, chunks[ci], s.stream, results, tb_buf, tb_off);
-            {
-                std::lock_guard<std::mutex> lk(sh.mu);
-                if (e != ALN_OK && sh.status == ALN_OK) { sh.status = e; sh.err = g_err; }
-                sh.slot_free[si] = 1;
-                chunks[ci] = Chunk();      // the plan is not needed any more
-            }
-            sh.cv.notify_all();
-        }
-    });
-    for (size_t ci = 0; ci < nc && st == ALN_OK; ++ci) {
-        Chunk &k = chunks[ci];
-        // (walk waves beside the LAST chunk's own fill, as a staged batch has them, were measured: 53.7 ms against 52.0 without)
-        st = chunk_plan(ctx, c, q_off, q_len, t_off, t_len, ranges[ci].first, ranges[ci].second, false, k);   // while the GPU works
-        if (st != ALN_OK) break;
-        const int si = (int)(ci % (size_t)ns);
-        {
-            std::unique_lock<std::mutex> lk(sh.mu);
-            sh.cv.wait(lk, [&] { return sh.slot_free[si] != 0 || sh.status != ALN_OK; });
-            if (sh.status != ALN_OK) break;
-            sh.slot_free[si] = 0;
-        }
-        Slot &s = *slots[si];
-        if ((st = slot_ensure(s, c, k, &need)) != ALN_OK) break;
-        if ((st = slot_upload(s, c, k, seqs, q_off, q_len, t_off, t_len, s.stream)) != ALN_OK) break;
-        // At most `depth` fills share the chip: chunk i's fill waits for the fill of chunk i - depth.  With every slot's fill
-        // started at once the chunks run in lockstep -- they share the chip equally, reach their tails together (a chunk's
-        // largest pairs take as long as the whole chunk), then all walk and copy while nothing fills.  Fewer at a time stay
-        // staggered: the oldest is in its tail while the younger ones fill the waves it leaves free (C5, 16 chunks: depth
-        // 1: 83 ms, 2: 53.7, 3: 52.6, 4 = every slot: 56.5).
-        hipEvent_t after = (ci >= depth && ns > (int)depth) ? slots[(ci - depth) % (size_t)ns]->ev_fill : nullptr;
-        if ((st = slot_launch(ctx, s, c, k, s.stream, nullptr, nullptr, after)) != ALN_OK) break;
-        {
-            std::lock_guard<std::mutex> lk(sh.mu);
-            sh.ready.push_back(ci);
-        }
-        sh.cv.notify_all();
-    }
-    const std::string my_err = g_err;
-    {
-        std::lock_guard<std::mutex> lk(sh.mu);
-        sh.done_issuing = true;
-    }
-    sh.cv.notify_all();
-    fetcher.join();
-    for (int i = 0; i < ns; ++i) (void)hipStreamSynchronize(slots[i]->stream);
-    if (st != ALN_OK) { g_err = my_err; return st; }
-    if (sh.status != ALN_OK) { g_err = sh.err; return sh.status; }
+    // ---- the devices of the context take the chunks from one queue; device 0's pipeline runs on the caller's thread
+    const size_t nd = std::min(ctx->devs.size(), nc);
+    std::vector<std::thread> others;
+    for (size_t d = 1; d < nd; ++d) others.emplace_back([&, d] { device_pipeline(ctx->devs[d], job); });
+    device_pipeline(ctx->devs[0], job);
+    for (auto &t : others) t.join();
+    if (job.status != ALN_OK) { g_err = job.err; return job.status; }
     return ALN_OK;
 }
 
 // ---------------------------------------------------------------- staged batch: one chunk resident in a private slot
 struct aln_batch {
-    aln_ctx *ctx = nullptr;
+    DevCtx *ctx = nullptr;           // a staged batch lives on ONE device: the context's first
     Call call;
     Chunk k;
     Slot *slot = nullptr;
@@ -932,11 +1023,11 @@ extern "C" aln_batch *aln_batch_create(aln_ctx *ctx, const aln_params *params, c
     if (!ctx || !params || (n_pairs && (!seqs || !q_off || !q_len || !t_off || !t_len))) { g_err = "null argument"; st = ALN_ERR_INVALID_ARGUMENT; }
     else {
         b = new aln_batch();
-        b->ctx = ctx;
-        hipError_t e = hipSetDevice(ctx->device);
+        b->ctx = ctx->devs[0];
+        hipError_t e = hipSetDevice(b->ctx->device);
         if (e != hipSuccess) st = fail(e, "hipSetDevice");
         if (st == ALN_OK) st = call_init(b->call, params, q_len, t_len, n_pairs, false);
-        if (st == ALN_OK) st = chunk_plan(ctx, b->call, q_off, q_len, t_off, t_len, 0, n_pairs, true, b->k);
+        if (st == ALN_OK) st = chunk_plan(b->ctx, b->call, q_off, q_len, t_off, t_len, 0, n_pairs, true, b->k);
         if (st == ALN_OK) {
             b->slot = new Slot();
             b->slot->pooled = false;
@@ -1053,13 +1144,14 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
     Call c;
     int st = call_init(c, &p, &ql, &tl, 1, h_matrix != nullptr);
     if (st != ALN_OK) { memset(out, 0, sizeof *out); out->status = st; return st; }
-    HIPCHK(hipSetDevice(ctx->device));
+    DevCtx *dev = ctx->next_device();                        // concurrent callers spread over the context's devices
+    HIPCHK(hipSetDevice(dev->device));
     Slot *sl[1];
-    pool_lease(ctx, 1, sl);
-    struct Release { aln_ctx *c; Slot **s; ~Release() { pool_release(c, s, 1); } } rel{ctx, sl};
+    pool_lease(dev, 1, sl);
+    struct Release { DevCtx *c; Slot **s; ~Release() { pool_release(c, s, 1); } } rel{dev, sl};
     Slot &s = *sl[0];
     Chunk k;
-    if ((st = chunk_plan(ctx, c, &qo, &ql, &to, &tl, 0, 1, false, k)) != ALN_OK) return st;
+    if ((st = chunk_plan(dev, c, &qo, &ql, &to, &tl, 0, 1, false, k)) != ALN_OK) return st;
     k.seq_direct = false;                                    // query and target are two caller buffers: gathered into staging
     k.seq_span = nq + M;
     k.descs[0].q_off = 0; k.descs[0].t_off = nq;
@@ -1070,7 +1162,7 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
         if (M) memcpy(h + nq, target, M);
     }
     if ((st = slot_upload(s, c, k, nullptr, &qo, &ql, &to, &tl, s.stream, true)) != ALN_OK) return st;
-    if ((st = slot_launch(ctx, s, c, k, s.stream, nullptr, nullptr)) != ALN_OK) { (void)hipStreamSynchronize(s.stream); return st; }
+    if ((st = slot_launch(dev, s, c, k, s.stream, nullptr, nullptr)) != ALN_OK) { (void)hipStreamSynchronize(s.stream); return st; }
     const size_t cap = N + M + 2;
     const uint64_t cells = (uint64_t)(N + 1) * (M + 1);
     const bool ok_shape = k.descs[0].status == ALN_OK;

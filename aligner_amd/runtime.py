@@ -38,6 +38,28 @@ def context(device=None):
         return h
 
 
+def context_multi(devices=None):
+    """One context spanning several GPUs of THIS process (aln_create_multi): `devices` is a list of device ids, None = every
+    visible device.  Batch calls on it are sharded chunk by chunk over the devices; single calls take the devices in turn.
+    (A list may name a device twice: two pools on one GPU -- used by the tests to run the sharded path on a one-GPU box.)"""
+    lib = _ffi.load()
+    key = ("multi",) + (tuple(int(d) for d in devices) if devices is not None else ("all",))
+    with _lock:
+        h = _ctx.get(key)
+        if h is None:
+            st = C.c_int(0)
+            if devices is None:
+                h = lib.aln_create_multi(0, None, C.byref(st))
+            else:
+                ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+                h = lib.aln_create_multi(len(devices), ids, C.byref(st))
+            if not h:
+                raise DeviceError(st.value, "aln_create_multi(%s) failed: %s [%s]" % (devices, _ffi.STATUS_NAMES.get(st.value, st.value),
+                                                                                  _ffi.last_error()))
+            _ctx[key] = h
+        return h
+
+
 def device_info(device=None):
     lib = _ffi.load()
     cus, hbm, name = C.c_int(0), C.c_size_t(0), C.create_string_buffer(128)
@@ -71,7 +93,8 @@ def make_params(semantics, del_, ext, matrix, heuristics_present=False, outputs=
     m = np.asarray(matrix, dtype=np.float64)
     if m.ndim != 2:
         raise AlignerError(ErrorKind.MatrixShapeError)
-    if m.strides[1] != 8 or m.strides[0] % 8 != 0 or m.strides[0] < 0:
+    # (a broadcast / transposed view has a row stride the C side would misread: 0 means "contiguous" there)
+    if m.strides[1] != 8 or m.strides[0] % 8 != 0 or m.strides[0] < 8 * m.shape[1]:
         m = np.ascontiguousarray(m)
     p = _ffi.Params(int(semantics), int(bool(heuristics_present)), float(del_), float(ext), m.ctypes.data,
                     m.shape[0], m.shape[1], m.strides[0] // 8, int(outputs), int(blank), int(bool(force_f64)),

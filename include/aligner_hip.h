@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ALN_ABI_VERSION 1
+#define ALN_ABI_VERSION 2
 
 /* Which reference routine is reproduced bit-for-bit. */
 enum aln_semantics {
@@ -91,15 +91,23 @@ typedef struct aln_pair_result {
     uint32_t flags;             /* bit0: integer kernels were used; bit1: the strip-pipelined single-pair route */
 } aln_pair_result;
 
-typedef struct aln_ctx aln_ctx;      /* one per process per GPU; thread-safe */
+typedef struct aln_ctx aln_ctx;      /* one per process: one GPU or a list of GPUs; thread-safe */
 typedef struct aln_batch aln_batch;  /* a batch of pairs staged in HBM */
 
-/* ---- context ---- */
+/* ---- context.  The reference runs its aligners on the caller's threads with no shared state (ten std::threads in
+ * statistics/mod.rs:255-286); here every thread of the process shares one context.  A context owns, per GPU, a pool of
+ * slots (device buffers, a stream, pinned staging) that calls lease -- nothing is allocated per call once the pool is warm.
+ * aln_create: one GPU.  aln_create_multi: the listed GPUs of this process (n_devices = 0: every visible one); single calls go
+ * to the devices in turn, a batch call is cut into chunks that the devices take from a common queue, and every device writes
+ * its chunks' summaries and strings straight into the caller's host buffers over its own PCIe link (the host array IS the
+ * gather; the multi-process form gathers device-side with RCCL, aligner_amd/distributed.py). ---- */
 aln_ctx *aln_create(int device_id, int *status);
+aln_ctx *aln_create_multi(int n_devices, const int *device_ids, int *status);
+int aln_device_count(const aln_ctx *ctx);
 void aln_destroy(aln_ctx *ctx);
 const char *aln_last_error(void);        /* thread-local text of the last ALN_ERR_DEVICE / _OOM */
 int aln_abi_version(void);
-int aln_device_info(aln_ctx *ctx, int *compute_units, size_t *hbm_bytes, char *name, size_t name_cap);
+int aln_device_info(aln_ctx *ctx, int *compute_units, size_t *hbm_bytes, char *name, size_t name_cap);   /* first device */
 
 /* ---- one pair, blocking (replaces one perform_alignment call).  q_aln / t_aln: capacity N+M+2 bytes each.
  * directions: optional (M+1)*(N+1) bytes; h_matrix: optional (M+1)*(N+1) doubles. ---- */
@@ -109,14 +117,26 @@ int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint8_t *query,
 
 /* ---- batch driver: semantics == map of aln_align_pair over independent pairs (the reference's only batch site is
  * statistics/mod.rs:255-286).  Pair i: query = seqs[q_off[i] .. +q_len[i]), target = seqs[t_off[i] .. +t_len[i]).
- * tb_buf (optional): pair i's aligned query at tb_off[i], aligned target at tb_off[i] + q_len[i] + t_len[i] + 2.
+ * All pointers are HOST memory (any malloc'ed / Vec memory; nothing has to be pinned).  The call is a pipeline: the batch is
+ * cut into chunks of the caller's pair order and chunk i+1 is uploaded, chunk i filled and traced back, chunk i-1 downloaded
+ * at the same time; residues are checked against the matrix shape on the device.
+ * tb_buf (optional): pair i's aligned query at tb_off[i], aligned target at tb_off[i] + q_len[i] + t_len[i] + 2; bytes of a
+ * string's capacity beyond aln_len are unspecified.  Any tb_off is accepted; the cumulative layout
+ * tb_off[i+1] = tb_off[i] + 2 * (q_len[i] + t_len[i] + 2) is copied back without a per-pair scatter.
  * ALN_PWM_LOCAL: q_len[i] is ignored (N = matrix cols); tb_off[i] must be a multiple of 4; pair i's uint32 column numbers
  * start at tb_off[i], its residue string at tb_off[i] + 4 * (cols + t_len[i] + 2). ---- */
 int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,
                     const uint64_t *q_len, const uint64_t *t_off, const uint64_t *t_len, size_t n_pairs,
                     aln_pair_result *results, uint8_t *tb_buf, const uint64_t *tb_off);
 
-/* ---- staged form of the batch driver: inputs resident in HBM, results left in HBM until fetched.
+/* The chunks aln_align_batch cuts these pairs into on a context of n_devices GPUs (host arithmetic only; no GPU needed):
+ * returns their number and writes up to cap (first pair, pair count) entries.  Chunks are ranges of the caller's pair order of
+ * 5e9 .. 1.6e10 cells; the devices take them from a common queue. */
+size_t aln_plan_chunks(const aln_params *params, const uint64_t *q_len, const uint64_t *t_len, size_t n_pairs, int n_devices,
+                       uint64_t *first, uint64_t *count, size_t cap);
+
+/* ---- staged form of the batch driver (one device: the context's first): inputs resident in HBM, results left in HBM
+ * until fetched.
  * create = validate + H2D + allocate; run = fill (+ exact re-fills) + traceback, asynchronous on `stream`
  * (a hipStream_t passed as void*, NULL = the context's own stream); fetch = D2H. ---- */
 aln_batch *aln_batch_create(aln_ctx *ctx, const aln_params *params, const uint8_t *seqs, const uint64_t *q_off,

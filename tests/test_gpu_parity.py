@@ -725,6 +725,39 @@ def test_pipelined_batch_call_chunks_layouts_and_bad_pairs(orc, blosum62, monkey
     got = _check_batch(orc, bad, _ffi.CORE_LOCAL, 11, 2, blosum62)
 
 
+def test_multi_device_context_shards_chunks(orc, blosum62, monkeypatch):
+    """aln_create_multi: one context over a LIST of GPUs; a batch call's chunks are taken from a common queue by one pipeline
+    per device, each writing its chunks straight into the caller's buffers.  Run over every visible device and -- so that the
+    sharded path also runs on a one-GPU box -- over a list naming device 0 three times (three pools, three pipelines):
+    same summaries and strings as the single-device call, for standard and foreign tb layouts and with bad pairs."""
+    import torch
+    rng = np.random.default_rng(17)
+    b = _spoil(workloads.c5_batch(n_pairs=900, lo=20, hi=420), rng)
+    monkeypatch.setenv("ALN_CHUNK_CELLS", str(b.cells // 23))
+    ref = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    visible = list(range(torch.cuda.device_count()))
+    for devs in (visible, [0, 0, 0]):
+        got = align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62, devices=devs)
+        assert (got.results == ref.results).all(), devs
+        for i in range(len(b)):
+            assert all((x == y).all() for x, y in zip(got.aligned(i), ref.aligned(i))), (devs, i)
+    cap = 2 * (b.q_len + b.t_len + np.uint64(2)) + np.uint64(3)
+    off = np.zeros(len(b), dtype=np.uint64)
+    off[::-1][1:] = np.cumsum(cap[::-1])[:-1]
+    got = align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62, devices=[0, 0, 0], tb_off=off)
+    assert (got.results == ref.results).all()
+    for i in range(0, len(b), 3):
+        assert all((x == y).all() for x, y in zip(got.aligned(i), ref.aligned(i))), i
+    # single calls on a multi-device context take the devices in turn
+    lib = _ffi.load()
+    assert lib.aln_device_count(runtime.context_multi([0, 0, 0])) == 3
+    q, t = b.query(1), b.target(1)
+    for _ in range(4):
+        res, qa, ta, _, _ = runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, blosum62, device=None)
+    want = orc.align(orc.CORE_LOCAL, q, t, 11, 2, blosum62)
+    assert res.score == want["score"] and qa.tolist() == want["qa"].tolist()
+
+
 def test_concurrent_callers_share_the_slot_pool(orc, blosum62):
     """Ten host threads call the library at once (statistics/mod.rs:255-286 runs ten aligner threads): the context's slots are
     leased per call, results equal the serial ones."""

@@ -116,7 +116,7 @@ def test_native_library_loads_and_exports_every_declared_symbol():
     assert declared == sorted(_ffi.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.aln_abi_version() == 1
+    assert lib.aln_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure_not_fallback(blosum62):
@@ -239,3 +239,27 @@ def test_evd_fit_keeps_the_references_loop_scoped_rebinding():
     finally:
         st.MAXITER = old
     assert seen == {"one", "several", "cap"}, seen
+
+
+def test_in_library_chunking_for_any_device_count():
+    """aln_plan_chunks (host arithmetic, no GPU): the chunks a batch call is cut into cover the pairs exactly once, in the
+    caller's order, stay within the cell bounds, and give every device of an 8-GPU context several chunks to take."""
+    lib = _ffi.load()
+    qlen, tlen = workloads.c5_lengths(100000)
+    ql, tl = qlen.astype(np.uint64), tlen.astype(np.uint64)
+    cells = (qlen * tlen).astype(np.float64)
+    p = _ffi.Params(_ffi.CORE_LOCAL, 0, 11.0, 2.0, None, 24, 24, 24, 3, 98, 0, 0, 0, 0)
+    for ndev in (1, 2, 3, 4, 8):
+        cap = 4096
+        first, count = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64)
+        n = lib.aln_plan_chunks(C.byref(p), ql.ctypes.data, tl.ctypes.data, len(ql), ndev, first.ctypes.data, count.ctypes.data, cap)
+        first, count = first[:n].astype(np.int64), count[:n].astype(np.int64)
+        assert first[0] == 0 and (first[1:] == np.cumsum(count)[:-1]).all() and count.sum() == len(ql)
+        per = np.array([cells[f:f + c].sum() for f, c in zip(first, count)])
+        assert per.max() <= 1.6e10 * 1.3 and per[:-1].min() >= 5e9 * 0.99
+        assert n >= 3 * ndev or per.max() <= 5.1e9          # every device gets about three chunks, or the chunks are at the floor
+        if ndev == 1:
+            assert n == 8
+    # a small batch is one chunk; nothing at all is no chunk
+    assert lib.aln_plan_chunks(C.byref(p), ql.ctypes.data, tl.ctypes.data, 500, 8, None, None, 0) == 1
+    assert lib.aln_plan_chunks(C.byref(p), ql.ctypes.data, tl.ctypes.data, 0, 1, None, None, 0) == 0
