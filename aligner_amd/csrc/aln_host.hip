@@ -53,6 +53,7 @@ extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N
 extern "C" void aln_launch_traceback_expand_single(const TraceArgs *a, uint32_t pair, hipStream_t s);
 extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_serial, hipStream_t s);
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s);
+extern "C" uint32_t aln_single_lds_bytes(uint32_t rows, uint32_t cols, uint32_t R, uint32_t N, uint32_t W);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s);
 
@@ -424,7 +425,10 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
             if (R != 1 && R != 2 && R != 4 && R != 8) R = 2;
             while ((d.M + 64 * R - 1) / (64 * R) > 4096 && R < 8) R *= 2;      // keep every strip's wave resident
             if ((d.M + 64 * R - 1) / (64 * R) > 4096) single = false;
-            if ((uint64_t)rows * cols * 4 + (uint64_t)cols * 64 * R + 2ull * (d.N + 192) + 1024 > 65536) single = false;   // LDS budget
+            // LDS: the whole query's profile offsets are staged (2 B per column) beside S and the waves' profiles; a workgroup may
+            // opt in to all 160 KiB of a CU (one wave per workgroup beyond ~43 000 columns, four below: aln_single_waves), which
+            // carries the route to ~77 000 columns.  Longer pairs take the batch kernel (one wave, slow but exact).
+            if (d.N > 100000u || aln_single_lds_bytes(rows, cols, R, d.N, 1) > 159u * 1024u) single = false;
             if (single) {
                 const uint32_t ns = (d.M + 64 * R - 1) / (64 * R);
                 dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * aln_uniform_strip_bytes(d.N, R));

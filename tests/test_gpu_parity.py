@@ -244,6 +244,52 @@ def test_c4_10k_pair_matches_oracle(orc, blosum62):
     check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=False)
 
 
+def test_c4_uniform_pair_the_bench_times(orc, blosum62):
+    """The uniform-random 10k x 10k pair bench.py times as "single_pair" (its score, 8806, is quoted in the bench line)."""
+    q, t = workloads.c4_pair(homolog=False)
+    res = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=False)
+    assert res.score == 8806.0 and res.flags & 2
+
+
+def test_long_pairs_beyond_the_old_column_limit(orc, blosum62):
+    """The single-pair route stages the whole query's profile offsets in LDS.  Up to r01 the host refused it above a 64 KiB
+    budget (N ~ 29 400 columns) and such a pair fell to the one-wave batch kernel; a workgroup now opts in to the CU's whole
+    160 KiB.  Bit-exact summaries and strings for 40 000 x 10 000 and 10 000 x 40 000 and at the old boundary +- 64, each on
+    the strip-pipelined route (flags bit 1); the oracle runs (dense f64 H, ~0.5 min each) go side by side on host threads."""
+    import threading
+    rng = np.random.default_rng(4040)
+    shapes = [(40000, 10000), (10000, 40000), (29376 - 64, 4160), (29376, 4160), (29376 + 64, 4160)]
+    cases = []
+    for N, M in shapes:
+        q = rng.integers(0, 20, N).astype(np.uint8)
+        # a homolog of the query's head keeps a long real alignment in the picture
+        t = workloads.mutate(q[:M] if M <= N else np.concatenate([q, rng.integers(0, 20, M - N).astype(np.uint8)]),
+                             1234 + N, 20, 0.10, 0.02, out_len=M)
+        cases.append((q, t))
+    refs = [None] * len(cases)
+
+    def run(i):
+        refs[i] = orc.align(orc.CORE_LOCAL, cases[i][0], cases[i][1], 11, 2, blosum62)
+    th = [threading.Thread(target=run, args=(i,)) for i in range(len(cases))]
+    [x.start() for x in th]
+    got = []
+    import time
+    for q, t in cases:
+        runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, blosum62)           # warm the slot
+        t0 = time.perf_counter()
+        got.append(runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, blosum62))
+        dt = time.perf_counter() - t0
+        gcups = len(q) * len(t) / dt / 1e9
+        assert got[-1][0].flags & 2, "not on the strip-pipelined route"
+        if len(q) * len(t) >= 4e8:
+            assert gcups >= 50.0, (len(q), len(t), gcups)                     # host call, upload and download included
+    [x.join() for x in th]
+    for (res, qa, ta, _, _), ref in zip(got, refs):
+        assert res.status == 0 and ref["status"] == 0
+        assert (res.score, res.f, (res.end_y, res.end_x), (res.start_y, res.start_x)) == (ref["score"], ref["f"], ref["end"], ref["start"])
+        assert qa.tolist() == ref["qa"].tolist() and ta.tolist() == ref["ta"].tolist()
+
+
 def test_c5_sample_matches_oracle(orc, blosum62):
     """BASELINE C5 at its real lengths (200..2000 aa) on a 1500-pair sample: every summary and both aligned strings.
     Exercises multi-strip pairs, the checkpointed first pass and the localized row-1 repair."""
