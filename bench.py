@@ -25,6 +25,10 @@ import time
 
 import numpy as np
 
+# the library asks the HIP runtime for 8 hardware queues when it is loaded before the runtime initialises (aln_host.hip); here
+# torch comes first, so the same request is made explicitly (never overriding the user's value)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -123,23 +127,58 @@ def small_configs(S, local_rank, stream, torch):
         sb.close()
         return dt, tm, r, dirs
 
-    # C2: one 1k x 1k protein pair, core local 11/2
+    def pair_walls(sem, q, t, d, e, M, reps=30, **kw):
+        runtime.align_pair(sem, q, t, d, e, M, device=local_rank, **kw)
+        walls = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            runtime.align_pair(sem, q, t, d, e, M, device=local_rank, **kw)
+            walls.append(time.perf_counter() - t0)
+        walls.sort()
+        return walls
+
+    # C2: one 1k x 1k protein pair, core local 11/2 -- the uniform pair (one fill pass) and the homolog variant (its row-1
+    # advice changes, so the strip pipeline runs twice)
+    for name, homolog in (("C2", False), ("C2_homolog", True)):
+        q, t = workloads.c2_pair(homolog=homolog)
+        one = PairBatch.from_pairs([(q, t)])
+        dt, tm, r, _ = staged(one, _ffi.CORE_LOCAL, 11, 2, S, 50)
+        walls = pair_walls(_ffi.CORE_LOCAL, q, t, 11, 2, S)
+        out[name] = {"workload": "one 1000 x %d protein pair (%s), core local, BLOSUM62, 11/2" % (
+                         len(t), "10 %% substitutions + 2 %% indels" if homolog else "uniform random"),
+                     "device_ms": round(tm["fill_ms"] + tm["traceback_ms"], 4), "fill_ms": round(tm["fill_ms"], 4),
+                     "traceback_ms": round(tm["traceback_ms"], 4), "fill_passes": int(r[0]["passes"] & 0x7f),
+                     "staged_run_ms": round(dt * 1e3, 4), "gcups_staged": round(one.cells / dt / 1e9, 3),
+                     "aln_align_pair_wall_ms_median": round(walls[len(walls) // 2] * 1e3, 4),
+                     "aln_align_pair_wall_ms_min": round(walls[0] * 1e3, 4), "score": float(r[0]["score"]),
+                     "status": int(r[0]["status"])}
+    # the same uniform pair with a real-valued matrix (what every HeuristicAligner iteration runs, heuristic/mod.rs:58-77): f64
+    # kernels; and with the full AlignmentResult (direction matrix from the fast kernels; H only from the generic ones)
     q, t = workloads.c2_pair(homolog=False)
-    one = PairBatch.from_pairs([(q, t)])
-    dt, tm, r, _ = staged(one, _ffi.CORE_LOCAL, 11, 2, S, 50)
-    runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, S, device=local_rank)
-    walls = []
-    for _ in range(30):
-        t0 = time.perf_counter()
-        runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, S, device=local_rank)
-        walls.append(time.perf_counter() - t0)
-    walls.sort()
-    out["C2"] = {"workload": "one 1000 x 1000 protein pair, core local, BLOSUM62, 11/2",
-                 "device_ms": round(tm["fill_ms"] + tm["traceback_ms"], 4), "fill_ms": round(tm["fill_ms"], 4),
-                 "traceback_ms": round(tm["traceback_ms"], 4), "kernel_launches_fill": tm["fill_launches"],
-                 "staged_run_ms": round(dt * 1e3, 4), "gcups_staged": round(one.cells / dt / 1e9, 3),
-                 "aln_align_pair_wall_ms_median": round(walls[len(walls) // 2] * 1e3, 4),
-                 "aln_align_pair_wall_ms_min": round(walls[0] * 1e3, 4), "score": float(r[0]["score"]), "status": int(r[0]["status"])}
+    cells = len(q) * len(t)
+    w = pair_walls(_ffi.CORE_LOCAL, q, t, 11.5, 2.25, S * 0.5, reps=10)
+    out["f64_pair"] = {"workload": "the C2 pair, real-valued matrix (BLOSUM62 x 0.5, del 11.5 / ext 2.25): f64 kernels",
+                       "aln_align_pair_wall_ms_median": round(w[len(w) // 2] * 1e3, 3), "gcups": round(cells / w[len(w) // 2] / 1e9, 3)}
+    w = pair_walls(_ffi.CORE_LOCAL, q, t, 11, 2, S, reps=10, want_directions=True)
+    out["pair_with_direction_matrix"] = {"workload": "the C2 pair + the (M+1) x (N+1) Direction bytes (fast kernels + unpack)",
+                                         "aln_align_pair_wall_ms_median": round(w[len(w) // 2] * 1e3, 3)}
+    w = pair_walls(_ffi.CORE_LOCAL, q, t, 11, 2, S, reps=5, want_directions=True, want_h=True)
+    out["pair_with_h_and_direction_matrix"] = {"workload": "the C2 pair + direction bytes + the f64 H matrix (generic kernels, 9 B per cell over PCIe)",
+                                               "aln_align_pair_wall_ms_median": round(w[len(w) // 2] * 1e3, 3)}
+    # PWM windows (the inner loop of latent-repeat-search): 100 000 windows of 330 nt against a 4 x 300 PWM, score only
+    from aligner_amd.pwm import align_windows
+    rng = np.random.default_rng(300)
+    pwm = rng.integers(-3, 4, (4, 300)).astype(np.float64)
+    chrom = rng.integers(0, 4, 100000 * 30 + 400).astype(np.uint8)
+    wins = [chrom[i * 30:i * 30 + 330] for i in range(100000)]
+    align_windows(wins[:2000], 3, 1, pwm, device=local_rank, want_traceback=False)
+    t0 = time.perf_counter()
+    resw, _ = align_windows(wins, 3, 1, pwm, device=local_rank, want_traceback=False)
+    dtw = time.perf_counter() - t0
+    out["pwm_windows"] = {"workload": "100000 windows of 330 nt x a 4 x 300 PWM, del 3 / ext 1, score only, host buffers in and out "
+                                      "(includes packing the windows in Python)",
+                          "ms": round(dtw * 1e3, 2), "gcups": round(100000 * 330 * 300 / dtw / 1e9, 2),
+                          "windows_ok": int((resw["status"] == 0).sum())}
     # C3: 10 000 nucleotide read pairs 150 x 150, core global, +5/-4, 10/1
     b3 = workloads.c3_batch(10000)
     dt, tm, r, dirs = staged(b3, _ffi.CORE_GLOBAL, 10, 1, nucleotide_matrix(), 50)
