@@ -40,7 +40,7 @@
         const uint32_t ss = (uint32_t)__builtin_amdgcn_readfirstlane((int)(seed + 5u));                        \
         __syncthreads();                                                                                       \
         const uint64_t t0 = __builtin_readcyclecounter();                                                      \
-        for (uint32_t i = 0; i < iters; ++i) asm volatile(R64(OP) OPERANDS);                                   \
+        for (uint32_t i = 0; i < iters; ++i) asm volatile(R64(OP) "1:\n\t" OPERANDS);                                   \
         const uint64_t t1 = __builtin_readcyclecounter();                                                      \
         const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;                                    \
         if ((threadIdx.x & 63u) == 0) out[wave] = t1 - t0;                                                     \
@@ -128,6 +128,20 @@
 #define OP_ADDIMM(i) "v_add_u32 %" S(i) ", -1, %" S(i) "\n\t"
 #define OP_ADDLIT(i) "v_add_u32 %" S(i) ", 0x12345, %" S(i) "\n\t"
 #define OP_ADDSGPR(i) "v_add_u32 %" S(i) ", %10, %" S(i) "\n\t"
+// mixes: does a scalar instruction of the same wave's stream cost the SIMD anything?
+#define OP_MAX3_SADD(i) "v_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\ts_add_u32 s2" S(i) ", s2" S(i) ", 1\n\t"
+#define OP_MAX3_SNOP(i) "v_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\ts_nop 0\n\t"
+#define OP_MAX3_SCMP_BR(i) "v_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\ts_cmp_eq_u32 s2" S(i) ", 77\n\ts_cbranch_scc1 1f\n\t"
+#define OP_MAX3_2SALU(i) "v_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\ts_add_u32 s2" S(i) ", s2" S(i) ", 1\n\ts_xor_b32 s2" S(i) ", s2" S(i) ", 5\n\t"
+#define OP_ADD_SADD(i) "v_add_u32 %" S(i) ", %" S(i) ", %8\n\ts_add_u32 s2" S(i) ", s2" S(i) ", 1\n\t"
+#define OP_MAX3_ADD(i) "v_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\tv_add_u32 %" S(i) ", %" S(i) ", %8\n\t"
+#define OP_MAX3_DEP(i) "v_max3_i32 %0, %0, %8, %9\n\t"
+#define OP_ADD_DEP(i) "v_add_u32 %0, %0, %8\n\t"
+#define OP_MAX3_DEP2(i) "v_max3_i32 %0, %0, %8, %9\n\tv_max3_i32 %1, %1, %8, %9\n\t"
+// VALU instructions under an EMPTY exec mask: does the SIMD skip them?  (8 v_max3 with exec = 0 per 1 with exec = all)
+#define OP_EXEC0(i) "s_mov_b64 s[22:23], exec\n\ts_mov_b64 exec, 0\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\ts_mov_b64 exec, s[22:23]\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\t"
+#define OP_EXECONE(i) "s_mov_b64 s[22:23], exec\n\ts_mov_b64 exec, 1\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\ts_mov_b64 exec, s[22:23]\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\t"
+#define OP_SAVEEXEC_ONLY(i) "s_mov_b64 s[22:23], exec\n\ts_mov_b64 exec, 0\n\ts_mov_b64 exec, s[22:23]\n\tv_max3_i32 %" S(i) ", %" S(i) ", %8, %9\n\t"
 // the fill kernel's core-local cell (aln_fast.h): cmp + cndmask + sdwa add + add + add3 + max3 + and_or + max_u32 +
 // alignbit + lshl_add + max  = 11 VALU on a chain of its own
 #define OP_CELL(i)                                                                                             \
@@ -176,6 +190,18 @@ PROBE(bfe_u32, OP_BFE, 1)
 PROBE(mad_u32_u24, OP_MAD, 1)
 PROBE(min_max_i32, OP_MINMAX, 2)
 PROBE(fill_cell_11, OP_CELL, 11)
+PROBE(mix_max3_plus_sadd, OP_MAX3_SADD, 1)
+PROBE(mix_max3_plus_snop, OP_MAX3_SNOP, 1)
+PROBE(mix_max3_plus_scmp_branch, OP_MAX3_SCMP_BR, 1)
+PROBE(mix_max3_plus_2salu, OP_MAX3_2SALU, 1)
+PROBE(mix_add_plus_sadd, OP_ADD_SADD, 1)
+PROBE(mix_max3_plus_vadd, OP_MAX3_ADD, 2)
+PROBE(dep_chain_max3, OP_MAX3_DEP, 1)
+PROBE(dep_chain_add, OP_ADD_DEP, 1)
+PROBE(dep_2chains_max3, OP_MAX3_DEP2, 2)
+PROBE(exec0_4max3_per_1, OP_EXEC0, 5)
+PROBE(exec1lane_4max3_per_1, OP_EXECONE, 5)
+PROBE(exec_toggle_plus_max3, OP_SAVEEXEC_ONLY, 1)
 PROBE(max_f32, OP_MAXF, 1)
 PROBE(min_f32, OP_MINF, 1)
 PROBE(max3_f32, OP_MAX3F, 1)
@@ -237,6 +263,8 @@ static const Entry entries[] = {
     E(cndmask_b32), E(cmp_eq_vcc), E(cmp_eq_sgpr), E(pk_add_i16), E(pk_max_i16), E(pk_add_u16), E(pk_sub_u16_clamp),
     E(fma_f32), E(add_f32), E(readlane), E(writelane), E(perm_b32), E(xor_b32), E(mov_b32), E(lshrrev_b32), E(bfe_u32),
     E(mad_u32_u24), E(min_max_i32), E(fill_cell_11),
+    E(exec0_4max3_per_1), E(exec1lane_4max3_per_1), E(exec_toggle_plus_max3),
+    E(mix_max3_plus_sadd), E(mix_max3_plus_snop), E(mix_max3_plus_scmp_branch), E(mix_max3_plus_2salu), E(mix_add_plus_sadd), E(mix_max3_plus_vadd), E(dep_chain_max3), E(dep_chain_add), E(dep_2chains_max3),
     E(max_f32), E(min_f32), E(max3_f32), E(med3_f32), E(max_f32_negmod), E(and_b32), E(or_b32), E(and_b32_imm), E(lshlrev_b32), E(ashrrev_i32), E(cndmask_vcc_src), E(cndmask_sgpr_src), E(cmp_gt_f32), E(cmp_gt_i32), E(sub_f32_abs_clamp), E(mul_f32), E(cvt_f32_ubyte1), E(cvt_f32_i32), E(cvt_i32_f32), E(fma_mix_f32), E(pk_add_f32), E(pk_fma_f32), E(pk_mov_b32), E(max_f64), E(add_f64), E(pk_max_f16), E(max_f16), E(max_i16), E(add_u16), E(add_co_u32), E(bfi_b32), E(or3_b32), E(lshl_or_b32), E(xad_u32), E(min3_i32), E(mul_lo_u32), E(mul_u32_u24), E(floor_f32), E(add_f32_dpp), E(add_u32_dpp_row_shr), E(mov_b32_sdwa), E(accvgpr_write), E(accvgpr_read), E(fma_f32_sgpr), E(fmac_f32), E(add_u32_inline_imm), E(add_u32_literal), E(add_u32_sgpr),
 };
 
