@@ -3,7 +3,7 @@
 # usage: tools/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/
 set -o pipefail
 TAG=${1:-run}; shift
-ARGS=${@:---pairs 20000 --steps 3 --warmup 1 --no-cpu-baseline --no-single-pair}
+ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-small-configs --no-end-to-end}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,4 +15,6 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_W
   rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$NAME -- python3 bench.py $ARGS > $OUT/bench_pmc_$NAME.log 2>&1 || { echo "pmc $NAME failed"; tail -3 $OUT/bench_pmc_$NAME.log; }
 done
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
+rm -rf $OUT/trace $OUT/pmc_*
 cat $OUT/summary.txt
