@@ -145,22 +145,27 @@ struct TraceSingleArgs {
     uint4 *seg;               // per strip {entry cy, entry cx, tag-string offset, valid}
 };
 
+__host__ __device__ constexpr inline uint32_t aln_spb(uint32_t R) { return R >= 5 ? 2u : R >= 3 ? 4u : 16u / R; }
 // stored tag -> Direction discriminant (enums.rs:9-15: Top=0 Left=1 Diagonal=2 Beginning=3)
 __host__ __device__ inline int aln_tag_to_dir(int t) { return t == 3 ? 3 : 2 - t; }
 __host__ __device__ inline int aln_dir_to_tag(int d) { return d == 3 ? 3 : 2 - d; }
 // bit position of cell (row r of the lane, wave step k) inside its packed word; lane l is active for steps l .. l+N-1
 __host__ __device__ inline uint32_t aln_dir_bitpos(uint32_t k, uint32_t r, uint32_t lane, uint32_t N, int R)
 {
-    const uint32_t spb = 16u / (uint32_t)R;
+    const uint32_t spb = aln_spb((uint32_t)R);
     const uint32_t bend = (k / spb) * spb + spb - 1, lend = lane + N - 1;
     const uint32_t e = bend < lend ? bend : lend;
     return 30u - 2u * ((e - k) * (uint32_t)R + ((uint32_t)R - 1u - r));
 }
-// rows handled per lane in the strip that starts `rem` rows before the end of the target
+// rows handled per lane in the strip that starts `rem` rows before the end of the target: the smallest R with 64 R >= rem.
+// (A strip costs R cells of issue per step whatever its number of busy lanes; with R in {1,2,4,8} only, the last strips of C5
+// were rounded up by 8 % of the batch's work; every R in 1..8 leaves 3 %.)  Steps per direction word: aln_spb(R), the
+// largest power of two <= 16 / R (16, 8, 4, 4, 2, 2, 2, 2): the step arithmetic of fill and walk stays shifts and masks, and
+// the words of R = 3, 5, 6, 7 simply leave their low bits unused (12, 10, 12, 14 of 16 cell slots filled).
 __host__ __device__ inline int aln_pick_r(uint32_t rem)
 {
-    const int r = rem > 256 ? 8 : rem > 128 ? 4 : rem > 64 ? 2 : 1;
-    return r > ALN_FULL_R ? ALN_FULL_R : r;
+    const int r = (int)((rem + 63u) / 64u);
+    return r > ALN_FULL_R ? ALN_FULL_R : (r < 1 ? 1 : r);
 }
 __host__ __device__ inline uint32_t aln_num_strips(uint32_t M) { return (M + ALN_STRIP_ROWS - 1) / ALN_STRIP_ROWS; }
 // blocks (of SPB steps) a strip of `nsteps` steps stores, padded to whole quads
@@ -172,9 +177,9 @@ __host__ __device__ inline uint64_t aln_dir_word_index(uint32_t k, uint32_t lane
     return ((uint64_t)(kb >> 2) * 64u + lane) * 4u + (kb & 3u);
 }
 // bytes of one full (R = 8) strip region: steps N+63, 2 steps per block, 256 B per block
-__host__ __device__ inline uint64_t aln_strip_bytes(uint32_t N) { return (uint64_t)aln_strip_blocks(N + 63, 16 / ALN_FULL_R) * 256u; }
+__host__ __device__ inline uint64_t aln_strip_bytes(uint32_t N) { return (uint64_t)aln_strip_blocks(N + 63, aln_spb(ALN_FULL_R)) * 256u; }
 // bytes of one strip of the uniform-R layout (single-pair kernel)
-__host__ __device__ inline uint64_t aln_uniform_strip_bytes(uint32_t N, uint32_t R) { return (uint64_t)aln_strip_blocks(N + 63, 16u / R) * 256u; }
+__host__ __device__ inline uint64_t aln_uniform_strip_bytes(uint32_t N, uint32_t R) { return (uint64_t)aln_strip_blocks(N + 63, aln_spb(R)) * 256u; }
 __host__ __device__ inline uint64_t aln_rowmajor_bytes(uint32_t N, uint32_t M)
 {
     return (uint64_t)(M + 1) * ((N + 4) / 4);

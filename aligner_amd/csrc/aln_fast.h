@@ -67,23 +67,28 @@ __device__ __forceinline__ void v_cell(int top, int left, int negp, int diag, ui
 }
 #undef ALN_CELL_ASM
 
-template <int R> struct ProfWord;
-template <> struct ProfWord<8> { using T = uint2; };
-template <> struct ProfWord<4> { using T = uint32_t; };
-template <> struct ProfWord<2> { using T = uint16_t; };
-template <> struct ProfWord<1> { using T = uint8_t; };
+// a lane's R profile bytes are read as one LDS word of RP = 1, 2, 4 or 8 bytes (R rounded up), RP-aligned
+template <int RP> struct ProfWordP;
+template <> struct ProfWordP<8> { using T = uint2; };
+template <> struct ProfWordP<4> { using T = uint32_t; };
+template <> struct ProfWordP<2> { using T = uint16_t; };
+template <> struct ProfWordP<1> { using T = uint8_t; };
+template <int R> struct ProfWord {
+    static constexpr int RP = R > 4 ? 8 : R > 2 ? 4 : R;
+    using T = typename ProfWordP<RP>::T;
+};
 
 // the 32-bit word of the profile read that holds row r's byte
 template <int R>
 __device__ __forceinline__ uint32_t prof_word(const typename ProfWord<R>::T &pw, int r)
 {
-    if constexpr (R == 8) return r < 4 ? pw.x : pw.y;
+    if constexpr (R > 4) return r < 4 ? pw.x : pw.y;
     else return (uint32_t)pw;
 }
 template <int R>
 __device__ __forceinline__ int prof_byte(const typename ProfWord<R>::T &pw, int r)
 {
-    if constexpr (R == 8) return (int)(int8_t)(((r < 4 ? pw.x : pw.y) >> (8 * (r & 3))) & 0xff);
+    if constexpr (R > 4) return (int)(int8_t)(((r < 4 ? pw.x : pw.y) >> (8 * (r & 3))) & 0xff);
     else return (int)(int8_t)(((uint32_t)pw >> (8 * r)) & 0xff);
 }
 
@@ -173,7 +178,10 @@ __device__ __forceinline__ uint64_t uniform64(const void *p) { return uniform64(
 // hot loop of every batch fill.
 template <int SEM, int R, bool SINGLE, bool FIRST, bool LAST, bool PWM = false>
 struct FastStrip {
-    static constexpr int SPB = 16 / R;
+    static constexpr int SPB = (int)aln_spb(R);
+    static constexpr int RP = ProfWord<R>::RP;             // bytes between two lanes' profile words
+    // steps per chunk of the end-cell tracker: the largest multiple of a quad's steps that 11 bits can number
+    static constexpr uint32_t CHUNK = (2048u / (4u * SPB)) * (4u * SPB);
     static constexpr uint32_t STRIP_ROWS = SINGLE ? 64u * R : (uint32_t)ALN_STRIP_ROWS;
     static constexpr bool LOCAL = (SEM == ALN_CORE_LOCAL || SEM == ALN_LEGACY_LOCAL);
     using PW = typename ProfWord<R>::T;
@@ -183,6 +191,7 @@ struct FastStrip {
     const int lane;
     const uint32_t N;
     uint32_t lb, rb, yb;
+    uint32_t chunk0;           // first step of the tracker's current chunk
     bool zsel_on, brow_bad, aborted;
     int Tl[R], rbv[R];
     int hdiag, bottom, qoff, inchunk, qchunk, outq;
@@ -212,7 +221,7 @@ struct FastStrip {
     uint32_t psel_lo, psel_hi;
     __device__ __forceinline__ PW pwm_select(uint32_t w4) const
     {
-        if constexpr (R == 8) return make_uint2(__builtin_amdgcn_perm(w4, w4, psel_lo), __builtin_amdgcn_perm(w4, w4, psel_hi));
+        if constexpr (R > 4) return make_uint2(__builtin_amdgcn_perm(w4, w4, psel_lo), __builtin_amdgcn_perm(w4, w4, psel_hi));
         else return (PW)__builtin_amdgcn_perm(w4, w4, psel_lo);
     }
 
@@ -226,7 +235,7 @@ struct FastStrip {
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
             if (!FIRST && !SINGLE) inchunk = load_boundary(xi);
             if (SEM == ALN_CORE_LOCAL && FIRST && in.hazard) advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
-            if (!SINGLE) qchunk = (xi + 1 < N) ? (PWM ? (int)in.pwm_words[xi + 1] : (int)in.q[xi + 1] * (64 * R)) : 0;
+            if (!SINGLE) qchunk = (xi + 1 < N) ? (PWM ? (int)in.pwm_words[xi + 1] : (int)in.q[xi + 1] * (64 * RP)) : 0;
         }
         const int sel = (int)(k & 63u);
         int top0;
@@ -247,7 +256,8 @@ struct FastStrip {
             if constexpr (PWM) pw = pwm_select((uint32_t)qoff); else pw = *reinterpret_cast<const PW *>(prow + qoff);
         }
         // end-cell tie-break term of this step: earlier steps win (core) / later steps win (legacy)
-        const int kterm = (SEM == ALN_CORE_LOCAL) ? (int)(2047u - (k & 2047u)) : (int)(k & 2047u);
+        const uint32_t kc = SINGLE ? (k & 2047u) : k - chunk0;             // step within the tracker's chunk
+        const int kterm = (SEM == ALN_CORE_LOCAL) ? (int)(2047u - kc) : (int)kc;
         const uint32_t xm1 = k - (uint32_t)lane;
         if (!MASKED || xm1 < N) {
             int top = topIn, diag = hdiag;
@@ -600,7 +610,7 @@ struct FastStrip {
         yb = y0 + (uint32_t)lane * R;
         lb = (rows - 1) / R; rb = (rows - 1) % R;
         zsel_on = (SEM == ALN_CORE_LOCAL) && LAST && in.hazard;
-        prow = in.prof + lane * R;
+        prow = in.prof + lane * RP;
 
         // ---- query profile of this strip's rows: P[c][row] = 4*S[t[row]][c] - 2  (int8), row-contiguous per code
         int tc[R];
@@ -626,10 +636,10 @@ struct FastStrip {
                 const uint32_t bte = (uint32_t)(4 * in.S[tc[r] + c] - 2) & 0xffu;
                 if (r < 4) lo |= bte << (8 * r); else hi |= bte << (8 * (r - 4));
             }
-            uint8_t *dst = in.prof + c * (64 * R) + lane * R;
-            if constexpr (R == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
-            else if constexpr (R == 4) *reinterpret_cast<uint32_t *>(dst) = lo;
-            else if constexpr (R == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)lo;
+            uint8_t *dst = in.prof + c * (64 * RP) + lane * RP;
+            if constexpr (RP == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+            else if constexpr (RP == 4) *reinterpret_cast<uint32_t *>(dst) = lo;
+            else if constexpr (RP == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)lo;
             else *dst = (uint8_t)lo;
         }
         hdiag = LOCAL || yb == 0 ? 2 : 2 + (int)yb * in.nd4;            // H[yb][0]; yb < M always for valid lanes
@@ -645,7 +655,7 @@ struct FastStrip {
             qoff = *reinterpret_cast<const uint16_t *>(qo_lane);                      // step 0: column -lane
             qv = *reinterpret_cast<const uint16_t *>(qo_lane + 2);                    // step 1
         } else {
-            qoff = (lane == 0) ? (PWM ? (int)in.pwm_words[0] : (int)in.q[0] * (64 * R)) : 0;
+            qoff = (lane == 0) ? (PWM ? (int)in.pwm_words[0] : (int)in.q[0] * (64 * RP)) : 0;
         }
         if (!SINGLE && PWM) pw = pwm_select((uint32_t)qoff);
         else pw = *reinterpret_cast<const PW *>(prow + qoff);
@@ -655,7 +665,8 @@ struct FastStrip {
                       (size_t)strip * (SINGLE ? (size_t)(aln_uniform_strip_bytes(N, R) / 16) : (size_t)(aln_strip_bytes(N) / 16)) + lane;
         const uint32_t nkb = aln_strip_blocks(nsteps, SPB);
         // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
-        const uint32_t kb_steady0 = min(nkb, (uint32_t)(64 / SPB));
+        // (block counts: a lane's 64th step is in block 63 / SPB; segment ends are whole quads)
+        const uint32_t kb_steady0 = min(nkb, ((uint32_t)((63 + SPB) / SPB) + 3u) & ~3u);
         uint32_t kb_steady1 = max(kb_steady0, min(nkb, (N / (4 * SPB)) * 4u));
         // core global, strip 0: step N - 1 reads the overwritten corner H[0][N] = -(N + 1) del (simple/mod.rs:62), which the
         // border group of the asm loop does not know: that quad stays with the C++ step
@@ -664,10 +675,11 @@ struct FastStrip {
         // checkpoint steps 64, 128, 256, 512.
         const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0;
         // checkpoints sit on quad boundaries: the first at max(16, one quad of 4 * SPB steps), then doubling up to 512
-        uint32_t next_ck = ckmode ? max(ALN_CK_FIRST, 4u * (uint32_t)SPB) : 0xffffffffu, slot = 0, chunk_base = 0;
+        uint32_t next_ck = ckmode ? ((ALN_CK_FIRST + 4u * SPB - 1u) / (4u * SPB)) * (4u * SPB) : 0xffffffffu, slot = 0, chunk_base = 0;
+        chunk0 = 0;
         uint32_t kb = 0;
         while (kb < nkb) {
-            uint32_t seg_end = min(nkb, (chunk_base + 2048u) / SPB);
+            uint32_t seg_end = min(nkb, (chunk_base + CHUNK) / SPB);
             if (next_ck != 0xffffffffu) seg_end = min(seg_end, next_ck / SPB);
             const uint32_t e0 = min(kb_steady0, seg_end), e1 = min(kb_steady1, seg_end);
             if constexpr (ASMPATH && !FIRST) {
@@ -723,9 +735,10 @@ struct FastStrip {
                     return o;
                 }
             }
-            if (kb * SPB == chunk_base + 2048u) {         // every semantics advances the chunk; only the local ones track an end cell
+            if (kb * SPB == chunk_base + CHUNK) {         // every semantics advances the chunk; only the local ones track an end cell
                 if (LOCAL) fold(o, chunk_base);
-                chunk_base += 2048u;
+                chunk_base += CHUNK;
+                chunk0 = chunk_base;
             }
         }
         if (SINGLE && !LAST && !(ASMPATH && !FIRST)) publish(nkb * SPB - 1);     // the last (up to 15) columns (the asm publishes after every unit)
@@ -752,18 +765,14 @@ __device__ __forceinline__ FastOut fast_strip(const FastIn &in, FastOut o, uint3
         FastStrip<SEM, ALN_FULL_R, false, false, false, PWM> f(in, s);
         return f.run(o);
     }
-    if (s == 0) {
-        if (R == 8) { FastStrip<SEM, 8, false, true, true, PWM> f(in, s); return f.run(o); }
-        if (R == 4) { FastStrip<SEM, 4, false, true, true, PWM> f(in, s); return f.run(o); }
-        if (R == 2) { FastStrip<SEM, 2, false, true, true, PWM> f(in, s); return f.run(o); }
-        FastStrip<SEM, 1, false, true, true, PWM> f(in, s);
-        return f.run(o);
+#define ALN_LAST_STRIP(RR) case RR: if (s == 0) { FastStrip<SEM, RR, false, true, true, PWM> f(in, s); return f.run(o); } \
+                          else { FastStrip<SEM, RR, false, false, true, PWM> f(in, s); return f.run(o); }
+    switch (R) {
+    ALN_LAST_STRIP(1) ALN_LAST_STRIP(2) ALN_LAST_STRIP(3) ALN_LAST_STRIP(4) ALN_LAST_STRIP(5) ALN_LAST_STRIP(6) ALN_LAST_STRIP(7)
+    default: if (s == 0) { FastStrip<SEM, 8, false, true, true, PWM> f(in, s); return f.run(o); }
+             else { FastStrip<SEM, 8, false, false, true, PWM> f(in, s); return f.run(o); }
     }
-    if (R == 8) { FastStrip<SEM, 8, false, false, true, PWM> f(in, s); return f.run(o); }
-    if (R == 4) { FastStrip<SEM, 4, false, false, true, PWM> f(in, s); return f.run(o); }
-    if (R == 2) { FastStrip<SEM, 2, false, false, true, PWM> f(in, s); return f.run(o); }
-    FastStrip<SEM, 1, false, false, true, PWM> f(in, s);
-    return f.run(o);
+#undef ALN_LAST_STRIP
 }
 
 // butterfly reduction of the per-lane end-cell candidates with the exact tie rule

@@ -1132,7 +1132,7 @@ extern "C" uint64_t aln_batch_direction_bytes(const aln_batch *b)
             const bool last = s + 1 == ns;
             const uint32_t rem = d.M - s * ALN_STRIP_ROWS;
             const int R = last ? aln_pick_r(rem) : ALN_FULL_R;
-            const uint32_t rows = std::min<uint32_t>(rem, 64u * R), L = (rows + R - 1) / R, spb = 16 / R;
+            const uint32_t rows = std::min<uint32_t>(rem, 64u * R), L = (rows + R - 1) / R, spb = aln_spb((uint32_t)R);
             total += (uint64_t)aln_strip_blocks(d.N + L - 1, spb) * 256u;
         }
     }

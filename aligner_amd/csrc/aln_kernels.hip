@@ -135,7 +135,7 @@ template <typename SC, int SEM, int R>
 __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, const bool last)
 {
     using O = ScOps<SC>;
-    constexpr int SPB = 16 / R;                       // steps per packed direction word
+    constexpr int SPB = (int)aln_spb(R);              // steps per packed direction word
     const int lane = w.lane;
     const uint32_t N = w.N, M = w.M;
     const uint32_t y0 = strip * ALN_STRIP_ROWS;
@@ -329,7 +329,7 @@ __device__ __forceinline__ bool adopt_advice_zdw(uint8_t *advice, const uint32_t
                                                  uint32_t &last_flip)
 {
     const uint32_t ns = aln_num_strips(M), rows_last = M - (ns - 1) * ALN_STRIP_ROWS;
-    const uint32_t R = (uint32_t)aln_pick_r(rows_last), lb = (rows_last - 1) / R, rb = (rows_last - 1) % R, spb = 16u / R;
+    const uint32_t R = (uint32_t)aln_pick_r(rows_last), lb = (rows_last - 1) / R, rb = (rows_last - 1) % R, spb = aln_spb(R);
     int mismatch = 0;
     uint32_t lf = 0;
     for (uint32_t x = 2 + lane; x <= N; x += 64) {
@@ -409,10 +409,16 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
                 const bool last = (s + 1 == ns);
                 if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
                 const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R;
-                if (R == 8) run_strip<SC, SEM, 8>(w, s, last);
-                else if (R == 4) run_strip<SC, SEM, 4>(w, s, last);
-                else if (R == 2) run_strip<SC, SEM, 2>(w, s, last);
-                else run_strip<SC, SEM, 1>(w, s, last);
+                switch (R) {
+                case 1: run_strip<SC, SEM, 1>(w, s, last); break;
+                case 2: run_strip<SC, SEM, 2>(w, s, last); break;
+                case 3: run_strip<SC, SEM, 3>(w, s, last); break;
+                case 4: run_strip<SC, SEM, 4>(w, s, last); break;
+                case 5: run_strip<SC, SEM, 5>(w, s, last); break;
+                case 6: run_strip<SC, SEM, 6>(w, s, last); break;
+                case 7: run_strip<SC, SEM, 7>(w, s, last); break;
+                default: run_strip<SC, SEM, 8>(w, s, last); break;
+                }
             }
             ++passes;
             __threadfence_block();
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(1024) void aln_single_finalize_kernel(SingleArgs a)
     // H[M][x] == 0 <=> the stored tag of cell (M, x) is 3; the last strip recorded the direction words of the lane that
     // owns row M, one per block
     const uint32_t rows_last = M - (a.ns - 1) * 64u * a.R;
-    const uint32_t lb = (rows_last - 1) / a.R, rb = (rows_last - 1) % a.R, spb = 16u / a.R;
+    const uint32_t lb = (rows_last - 1) / a.R, rb = (rows_last - 1) % a.R, spb = aln_spb(a.R);
     const uint32_t *zdw = reinterpret_cast<const uint32_t *>(a.zrow);
     auto bottom_zero = [&](uint32_t x) -> uint8_t {                 // x = 1 .. N
         const uint32_t k = x - 1 + lb;
@@ -903,7 +909,7 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
     }
     const uint32_t lane = i / R, r = i % R;
     const uint32_t k = (x - 1) + lane;
-    const uint32_t spb = 16 / R;
+    const uint32_t spb = aln_spb((uint32_t)R);
     const uint32_t *wbase = reinterpret_cast<const uint32_t *>(base + strip * strip_bytes);
     const uint32_t word = wbase[aln_dir_word_index(k, lane, spb)];
     return aln_tag_to_dir((int)((word >> aln_dir_bitpos(k, r, lane, d.N, R)) & 3u));
@@ -913,26 +919,26 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
 struct StripView {
     const uint32_t *wbase;
     uint32_t y0;        // rows of the strip are y0+1 .. y0+rows
-    uint32_t lgR;       // log2(rows per lane)
+    uint32_t R;         // rows per lane (1..8; the uniform layout of the single-pair route: a power of two)
+    uint32_t lgS;       // log2(steps per direction word)
 };
 __device__ __forceinline__ StripView strip_view(const uint8_t *dirs, const PairDesc &d, uint32_t y)
 {
     StripView v;
     const uint8_t *base = dirs + d.dir_off;
     if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) {
-        const uint32_t R = (d.layout >> 8) & 0xffu;
-        v.lgR = 31u - (uint32_t)__builtin_clz(R);
-        const uint32_t strip = (y - 1) >> (6 + v.lgR);
-        v.y0 = strip << (6 + v.lgR);
-        v.wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_uniform_strip_bytes(d.N, R));
+        v.R = (d.layout >> 8) & 0xffu;
+        const uint32_t strip = (y - 1) / (64u * v.R);
+        v.y0 = strip * 64u * v.R;
+        v.wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_uniform_strip_bytes(d.N, v.R));
     } else {
         const uint32_t strip = (y - 1) / ALN_STRIP_ROWS;
         const uint32_t ns = aln_num_strips(d.M);
-        const uint32_t R = (strip + 1 == ns) ? (uint32_t)aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : (uint32_t)ALN_FULL_R;
-        v.lgR = 31u - (uint32_t)__builtin_clz(R);
+        v.R = (strip + 1 == ns) ? (uint32_t)aln_pick_r(d.M - strip * ALN_STRIP_ROWS) : (uint32_t)ALN_FULL_R;
         v.y0 = strip * ALN_STRIP_ROWS;
         v.wbase = reinterpret_cast<const uint32_t *>(base + strip * aln_strip_bytes(d.N));
     }
+    v.lgS = 31u - (uint32_t)__builtin_clz(aln_spb(v.R));
     return v;
 }
 
@@ -964,13 +970,12 @@ __device__ __forceinline__ void tb_walk_pair(const TraceArgs &a, uint32_t pair)
         // The walk is one dependent chain: ~a quarter of a load per step (a lane's quad -- 4 blocks, 16 B -- covers 64/R
         // consecutive steps of R rows and stays in registers until the path leaves it) and the instructions between two
         // loads, which a lone wave issues at one per ~4.6 cycles.  So the step is kept short: the state is (row within the
-        // strip, column - 1), both signed -- one sign test catches "left the strip upwards" and both borders --, and the
-        // tag's position in the quad is 2 * ((k mod 64/R) * R + r): within a block the words fill from bit 0 upwards in
-        // step-major order (aln_dir_bitpos), except in a lane's last, right-aligned block (shift by R per missing step).
+        // strip, column - 1), both signed -- one sign test catches "left the strip upwards" and both borders.
         if (cy != 0 && cx != 0) {
             StripView sv = strip_view(a.dirs, d, cy);
             int iy = (int)(cy - 1 - sv.y0), cxm = (int)cx - 1;
-            uint32_t lgR = sv.lgR, rmask = (1u << lgR) - 1u, qsh = 6u - lgR, kqmask = (1u << qsh) - 1u, bmask = (16u >> lgR) - 1u;
+            // rows per lane R is any of 1..8: lane = iy / R by multiplication (iy < 512), everything about the steps by shifts
+            uint32_t R = sv.R, rinv = (65535u + R) / R, lgS = sv.lgS, qsh = lgS + 2u, bmask = (1u << lgS) - 1u;
             const uint4 *wq = reinterpret_cast<const uint4 *>(sv.wbase);
             const uint32_t Nm1 = N - 1u;
             uint32_t qcur = 0xffffffffu;
@@ -982,18 +987,21 @@ __device__ __forceinline__ void tb_walk_pair(const TraceArgs &a, uint32_t pair)
                     if (cy == 0 || cx == 0) break;
                     sv = strip_view(a.dirs, d, cy);
                     iy = (int)(cy - 1 - sv.y0);
-                    lgR = sv.lgR; rmask = (1u << lgR) - 1u; qsh = 6u - lgR; kqmask = (1u << qsh) - 1u; bmask = (16u >> lgR) - 1u;
+                    R = sv.R; rinv = (65535u + R) / R; lgS = sv.lgS; qsh = lgS + 2u; bmask = (1u << lgS) - 1u;
                     wq = reinterpret_cast<const uint4 *>(sv.wbase);
                     qcur = 0xffffffffu;
                 }
-                const uint32_t lane = (uint32_t)iy >> lgR, r = (uint32_t)iy & rmask;
+                const uint32_t lane = ((uint32_t)iy * rinv) >> 16, r = (uint32_t)iy - lane * R;
                 const uint32_t k = (uint32_t)cxm + lane;
                 const uint32_t qi = ((k >> qsh) << 6) + lane;
                 if (qi != qcur) { quad = wq[qi]; qcur = qi; }
+                // the cell's tag sits at bit 32 - 2 R (m + 1) + 2 r of its word, m = steps of this lane left in the block
+                // after step k (aln_dir_bitpos); the word is number (k >> lgS) & 3 of the quad
                 const uint32_t lend = lane + Nm1;
-                const uint32_t idx = (((k & kqmask) << lgR) | r) + ((max(k | bmask, lend) - lend) << lgR);
-                const uint64_t half = (idx & 32u) ? (((uint64_t)quad.w << 32) | quad.z) : (((uint64_t)quad.y << 32) | quad.x);
-                const uint32_t tag = (uint32_t)(half >> ((2u * idx) & 63u)) & 3u;
+                const uint32_t m = min(k | bmask, lend) - k;
+                const uint32_t j = (k >> lgS) & 3u;
+                const uint64_t half = (j & 2u) ? (((uint64_t)quad.w << 32) | quad.z) : (((uint64_t)quad.y << 32) | quad.x);
+                const uint32_t tag = (uint32_t)(half >> (32u * (j & 1u) + 32u - 2u * R * (m + 1u) + 2u * r)) & 3u;
                 if (tag == 3u) {                            // Beginning
                     cy = (uint32_t)(iy + 1) + sv.y0; cx = (uint32_t)(cxm + 1);
                     break;
