@@ -76,7 +76,8 @@ struct FillArgs {
     uint32_t pwm;             // 1: position-weight-matrix scoring: S[t[y-1]][x-1], the query codes are the column indices
     const uint32_t *pwm_words;// fast path: per column the four int8 scores 4*s - 2 of residues 0..3, packed
     uint32_t no_repair;       // 1: disable the localized strip-0 repair (testing: full re-fills only)
-    uint32_t ck_bytes;        // fast path: bytes of the checkpoint + strip-0 bottom-row areas in each wave's scratch
+    uint32_t cascade_rows;    // fast path: boundary rows in each wave's scratch: 1 = one row used in place; 2 = strip 0's bottom row
+                              // keeps a row of its own (hazard pairs: the localized repair compares against it)
     uint32_t zrow_bytes;      // bytes of the bottom-row record in each wave's scratch (bytes per column, or one direction word per block)
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
     uint8_t blank;
@@ -107,6 +108,7 @@ struct SingleArgs {
 
 // strip 0 of a hazard pair checkpoints its lane state at steps max(16, one quad), then doubling, up to 512
 #define ALN_CK_SLOTS 6
+#define ALN_CASCADE_ROWS 2u
 #define ALN_CK_FIRST 16u
 
 struct TraceArgs {

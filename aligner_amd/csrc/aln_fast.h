@@ -125,7 +125,8 @@ struct FastIn {
     uint8_t *prof;            // LDS, this wave's profile
     int nd4, ne4;             // -4*del, -4*ext
     uint32_t *dirw;
-    int *brow, *brow0;        // boundary row (in place) / copy of strip 0's bottom row from the checkpointed pass
+    int *brow_in, *brow_out;  // batch kernels: the row above this strip / this strip's bottom row (one row used in place; for hazard
+                              // pairs strip 0's bottom row keeps a row of its own: the repair compares against it)
     uint8_t *advice, *zrow;
     int *ckpt;
     bool hazard;
@@ -135,7 +136,7 @@ struct FastIn {
     bool pwm;                 // position-weight-matrix scoring (batch kernels only)
     const uint32_t *pwm_words;// per column: int8 scores 4*s - 2 of residues 0..3
     int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair
-    uint32_t last_flip;
+    uint32_t last_flip;       // repair: last column whose input to this strip (row-1 advice, or the row above) differs from the checkpointed pass
     uint16_t *qo_pad;         // single-pair kernel: LDS, q[x] * 64R at index x + 63, zeros elsewhere (N + 192 entries)
     int *bring;               // single-pair kernel: LDS, 2 x 64 ints
     const uint32_t *gin;      // single-pair kernel: granule rows
@@ -153,6 +154,7 @@ struct FastOut {
     int corner;
     bool repaired, brow_bad, aborted;
     uint32_t ck_slot;         // repair pass: index of the checkpoint (step 16, 32, 64, ... 512 for R = 8) at which the lane state re-converged
+    uint32_t c_out;           // repair pass: last column in which this strip's bottom row changed (0: it did not)
 };
 
 // a better-than-b for the local end cell, values in any monotone form
@@ -192,6 +194,7 @@ struct FastStrip {
     const uint32_t N;
     uint32_t lb, rb, yb;
     uint32_t chunk0;           // first step of the tracker's current chunk
+    uint32_t cchg;             // repair: last column whose bottom-row cell changed (lane 63)
     bool zsel_on, brow_bad, aborted;
     int Tl[R], rbv[R];
     int hdiag, bottom, qoff, inchunk, qchunk, outq;
@@ -214,7 +217,7 @@ struct FastStrip {
     bool ring_staged;          // LDS hand-off: the C++ step has already taken the next group out of the ring (it is in bring)
 
     __device__ __forceinline__ FastStrip(const FastIn &i, uint32_t s)
-        : in(i), strip(s), lane(i.lane), N(i.N), brow_bad(false), aborted(false) {}
+        : in(i), strip(s), lane(i.lane), N(i.N), cchg(0), brow_bad(false), aborted(false) {}
 
     // PWM scoring: the flowing register holds the column's four packed scores; one v_perm per four rows picks each
     // row's byte by its residue code -- the result has the layout of a profile read
@@ -226,7 +229,7 @@ struct FastStrip {
     }
 
     // batch kernels: next 64 columns of the row above this strip (T form), one per lane
-    __device__ __forceinline__ int load_boundary(uint32_t xi) { return (xi < N) ? in.brow[xi + 1] : 2; }
+    __device__ __forceinline__ int load_boundary(uint32_t xi) { return (xi < N) ? in.brow_in[xi + 1] : 2; }
 
     template <bool MASKED>
     __device__ __forceinline__ void step(const uint32_t k)
@@ -308,11 +311,9 @@ struct FastStrip {
             bottom = Tl[R - 1];
             if (!SINGLE && !last && lane == 63) {
                 const uint32_t x = xm1 + 1;
-                if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 2) { if (in.brow0[x] != bottom) brow_bad = true; }
-                else {
-                    in.brow[x] = bottom;
-                    if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 1) in.brow0[x] = bottom;
-                }
+                // repair (strip 0): the row is the checkpointed pass's; a cell that comes out different ends the repair
+                if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 2) { if (in.brow_out[x] != bottom) cchg = x; }
+                else in.brow_out[x] = bottom;
             }
         }
         // bottom row to the strip below: lane 63's newest cell enters a 64-deep lane shift register (DPP wave_shl:1)
@@ -585,15 +586,30 @@ struct FastStrip {
     }
 
     // Lane state at a block boundary (direction word flushed, input chunks about to be reloaded): everything the
-    // rest of the strip depends on besides the inputs.  save = store it, !save = "is it identical to the stored one".
-    __device__ __forceinline__ bool checkpoint(uint32_t slot, bool save)
+    // rest of the strip depends on besides the inputs.  save = store it; !save = "is the DP state identical to the stored
+    // one".  The end-cell tracker's registers need not re-converge: `tracker` says whether they differ from the stored
+    // ones, and `stale` whether a stored candidate that the repaired prefix no longer produces is this lane's running
+    // winner (then the prefix's contribution cannot be taken back out of `o`, and the caller re-fills the pair).
+    __device__ __forceinline__ bool checkpoint(uint32_t slot, bool save, const FastOut &o, bool &tracker, bool &stale)
     {
         int *base = in.ckpt + slot * (18 * 64) + lane;
         bool same = true;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (save) { base[(2 * r) * 64] = Tl[r]; base[(2 * r + 1) * 64] = rbv[r]; }
-            else same = same && base[(2 * r) * 64] == Tl[r] && base[(2 * r + 1) * 64] == rbv[r];
+            else {
+                same = same && base[(2 * r) * 64] == Tl[r];
+                const int old = base[(2 * r + 1) * 64];
+                if (old != rbv[r]) {
+                    tracker = true;
+                    const uint32_t y = yb + 1 + r;
+                    if (old != INT_MIN && y <= in.M) {
+                        const uint32_t kk = (uint32_t)old & 2047u;
+                        const uint32_t k = (SEM == ALN_CORE_LOCAL) ? 2047u - kk : kk;      // checkpoints lie in the tracker's first chunk
+                        if ((old >> 11) == o.bv && y == o.by && k - (uint32_t)lane + 1 == o.bx) stale = true;
+                    }
+                }
+            }
         }
         if (save) { base[16 * 64] = hdiag; base[17 * 64] = bottom; }
         else same = same && base[16 * 64] == hdiag && base[17 * 64] == bottom;
@@ -716,24 +732,24 @@ struct FastStrip {
             for (; kb < e1; kb += 4) quad<false>(dirq, kb);
             for (; kb < seg_end; kb += 4) quad<true>(dirq, kb);
             if (ckmode && kb < nkb && kb * SPB == next_ck) {
-                if (in.ck_mode == 1) checkpoint(slot, true);
-                else if (__all(checkpoint(slot, false)) && in.last_flip <= next_ck) {
-                    // every lane is in exactly the state the checkpointed pass had here and no advice differs from
-                    // here on: the rest of this strip -- and so of the whole fill -- is unchanged
-                    o.repaired = true;
-                    o.ck_slot = slot;
-                    o.brow_bad = o.brow_bad || brow_bad;
+                bool tracker = false, stale = false;
+                if (in.ck_mode == 1) checkpoint(slot, true, o, tracker, stale);
+                else if (__all(checkpoint(slot, false, o, tracker, stale)) && in.last_flip <= next_ck) {
+                    // every lane's DP state is exactly what the checkpointed pass had here and no input differs from here
+                    // on: the rest of this strip is unchanged.  The end-cell candidates of the repaired prefix replace the
+                    // checkpointed pass's -- possible unless one of those is a lane's running winner.
+                    if (!__any(stale)) {
+                        if (__any(tracker)) fold(o, 0);
+                        o.repaired = true;
+                        o.ck_slot = slot;
+                        o.c_out = (uint32_t)__builtin_amdgcn_readlane((int)cchg, 63);
+                    }
                     return o;
                 }
                 ++slot;
                 next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
-                // a repair that has run out of checkpoints, or has moved the strip's bottom row, cannot succeed any more:
-                // stop here (in this mode every step of lane 63 waits for a load of the old bottom row -- run to its end,
-                // a failed repair cost as much as a full pass)
-                if (in.ck_mode == 2 && (next_ck == 0xffffffffu || __any(brow_bad))) {
-                    o.brow_bad = o.brow_bad || brow_bad;
-                    return o;
-                }
+                // a repair that has run out of checkpoints cannot succeed any more: stop here (the caller re-fills the pair)
+                if (in.ck_mode == 2 && next_ck == 0xffffffffu) return o;
             }
             if (kb * SPB == chunk_base + CHUNK) {         // every semantics advances the chunk; only the local ones track an end cell
                 if (LOCAL) fold(o, chunk_base);

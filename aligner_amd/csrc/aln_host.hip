@@ -366,7 +366,7 @@ struct Chunk {
     std::vector<uint32_t> single_pairs, single_r;   // pairs routed to the single-pair (one wave per strip) kernel
     size_t n_small = 0;
     uint64_t cells = 0, max_cells = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, hmat_elems = 0;
-    uint32_t max_len = 1, grid = 1, zrow_bytes = 0, lds_bytes = 0, prof_stride = 0, tb_waves = 0, single_max_n = 0;
+    uint32_t max_len = 1, grid = 1, zrow_bytes = 0, lds_bytes = 0, prof_stride = 0, tb_waves = 0, single_max_n = 0, cascade_rows = 1;
     uint64_t scratch_stride = 0, granule_bytes = 0, tbmap_entries = 0;
     size_t counter_bytes = 256;
     bool overlap = false;             // walk waves beside the fill (in-kernel overlapped traceback)
@@ -509,13 +509,15 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
     const uint64_t sc_size = c.is_int ? 4 : 8;
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
-    // + checkpoints of strip 0's lane state (18 ints x 64 lanes each) and a copy of strip 0's bottom row (fast path)
-    const uint64_t ck_bytes = c.fast ? ((uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 + ((((uint64_t)max_len + 66) * 4 + 63) & ~63ull)) : 0;
+    // fast path, core local with del != ext: strip 0's bottom row keeps a row of its own and strip 0 checkpoints its lane state
+    // (18 ints x 64 lanes per checkpoint): the localized repair of the row-1 hazard, do_pair_fast
+    k.cascade_rows = (c.fast && c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext) ? ALN_CASCADE_ROWS : 1u;
+    const uint64_t ck_bytes = c.fast ? (uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 : 0;
     // bottom-row record: one byte per column (generic kernels) or one direction dword per block of the last strip (fast
     // path: at most (max_len + 63) / 2 + 4 blocks)
     const uint64_t zrow_bytes = std::max<uint64_t>(adv_bytes, (4ull * (((uint64_t)max_len + 63) / 2 + 8) + 63) & ~63ull);
     k.zrow_bytes = (uint32_t)zrow_bytes;
-    k.scratch_stride = brow_bytes + adv_bytes + zrow_bytes + ck_bytes;
+    k.scratch_stride = (uint64_t)k.cascade_rows * brow_bytes + adv_bytes + zrow_bytes + ck_bytes;
     k.lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
     k.prof_stride = 0;
     if (c.fast && !pwm) { k.prof_stride = cols * 64u * ALN_FULL_R; k.lds_bytes += 4u * k.prof_stride; }
@@ -650,6 +652,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     fa.seqs = s.seqs.as<uint8_t>(); fa.descs = s.descs.as<PairDesc>(); fa.order = s.order.as<uint32_t>(); fa.n_pairs = (uint32_t)k.n_small;
     fa.counter = s.counter.as<uint32_t>(); fa.dirs = s.dirs.as<uint8_t>(); fa.results = s.results.as<aln_pair_result>();
     fa.scratch = s.scratch.as<uint8_t>(); fa.scratch_stride = k.scratch_stride; fa.max_len = k.max_len; fa.zrow_bytes = k.zrow_bytes;
+    fa.cascade_rows = k.cascade_rows;
     fa.matrix = s.matrix.p; fa.rows = c.rows; fa.cols = c.cols; fa.prof_stride = k.prof_stride;
     fa.del = c.p.del; fa.ext = c.p.ext; fa.semantics = c.semantics;
     fa.max_passes = c.p.max_passes; fa.force_serial = c.p.force_serial;
@@ -985,9 +988,10 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
             need.tb_bytes = std::max(need.tb_bytes, tb);
             need.tag_bytes = std::max(need.tag_bytes, tags);
             // per wave: boundary row, advice, bottom-row record, checkpoints (chunk_plan)
-            const uint64_t stride = (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull) +
+            const uint64_t nrows = (c.fast && c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext) ? ALN_CASCADE_ROWS : 1u;
+            const uint64_t stride = nrows * (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull) +
                                     std::max<uint64_t>((mlen + 66 + 63) & ~63ull, (4 * ((mlen + 63) / 2 + 8) + 63) & ~63ull) +
-                                    (c.fast ? ((uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 + (((mlen + 66) * 4 + 63) & ~63ull)) : 0);
+                                    (c.fast ? (uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 : 0);
             need.scratch = std::max(need.scratch, (uint64_t)max_cus * 4 * 4 * stride);
         }
     }

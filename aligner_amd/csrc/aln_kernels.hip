@@ -457,8 +457,16 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
 // sit next to the left border, so a mismatch is repaired by re-running only the leading columns of strip 0 until its
 // lane state rejoins the checkpoint (localized repair); anything else escalates to full re-fills and finally to the
 // strict reference-order routine.
+// what a wave's scratch holds for the fast kernels (aln_fill_fast_kernel sets it up)
+struct FastScratch {
+    int *rows;                // boundary rows, `nrows` of them, row_ints apart
+    uint32_t row_ints, nrows;
+    int *ckpt;                // checkpoint sets, one per row, ck_ints apart
+    uint32_t ck_ints;
+};
+
 template <int SEM, bool PWM>
-__device__ __forceinline__ bool do_pair_fast(FastIn in, const FillArgs &a, PairDesc &desc, aln_pair_result &res, int del, int ext)
+__device__ __forceinline__ bool do_pair_fast(FastIn in, const FastScratch &fs, const FillArgs &a, PairDesc &desc, aln_pair_result &res, int del, int ext)
 {
     const int lane = in.lane;
     const uint32_t N = desc.N, M = desc.M;
@@ -480,16 +488,25 @@ __device__ __forceinline__ bool do_pair_fast(FastIn in, const FillArgs &a, PairD
 
     const uint32_t ns = aln_num_strips(M);
     const uint32_t max_passes = a.max_passes ? a.max_passes : 4u;
-    const bool can_repair = in.hazard && !a.no_repair;
+    // repairable: strip 0's bottom row stays as the checkpointed pass wrote it (row 0); the strips below pass theirs through
+    // row 1 in place
+    const bool can_repair = in.hazard && !a.no_repair && (ns == 1 || fs.nrows >= 2);
+    auto strip_io = [&](uint32_t s) {
+        const uint32_t ri = (can_repair && s) ? 1u : 0u, rp = (can_repair && s > 1) ? 1u : 0u;
+        in.brow_in = fs.rows + (size_t)rp * fs.row_ints;
+        in.brow_out = fs.rows + (size_t)ri * fs.row_ints;
+        in.ckpt = fs.ckpt;
+    };
     uint32_t passes = 0;
     bool converged = false;
     FastOut o;
     for (;;) {                                           // full passes
-        o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0;
-        in.ck_mode = (passes == 0 && can_repair) ? 1 : 0;
+        o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0;
         for (uint32_t s = 0; s < ns; ++s) {
             const bool last = (s + 1 == ns);
             if (s > 0) __threadfence_block();            // strip s reads the boundary row strip s-1 stored
+            strip_io(s);
+            in.ck_mode = (passes == 0 && can_repair && s == 0) ? 1 : 0;     // strip 0 of the first pass saves its checkpoints
             o = fast_strip<SEM, PWM>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R);
         }
         ++passes;
@@ -499,32 +516,40 @@ __device__ __forceinline__ bool do_pair_fast(FastIn in, const FillArgs &a, PairD
         converged = adopt_advice_zdw(in.advice, reinterpret_cast<const uint32_t *>(in.zrow), N, M, lane, last_flip);
         if (converged) break;
         if (passes == 1 && can_repair) {
+            // Localized repair.  The new advice perturbs strip 0 from column last_flip's step on; strip 0 re-runs its leading
+            // columns until its lane state rejoins a checkpoint (the end-cell candidates of the re-run prefix replace the
+            // checkpointed ones).  If its bottom row changed on the way, the strips below would have to follow -- measured on
+            // C5: a perturbation that reaches the bottom of strip 0 does not die out within the 512 checkpointed steps of any
+            // strip (a cascade through per-strip checkpoints never once re-converged), so that case is re-filled in full.
             uint32_t repairs = 0;
-            while (!converged && repairs < 8 && last_flip <= 512) {     // 512 = the last checkpoint
+            bool failed = false;
+            while (!converged && !failed && repairs < 8) {
                 ++repairs;
-                passes += 0x100u;                        // repairs are counted in bits 8..15
-                in.ck_mode = 2; in.last_flip = last_flip;
+                passes += 0x100u;                        // repair rounds are counted in bits 8..15
+                if (last_flip > 512u) { failed = true; passes |= 0x100000u; break; }    // beyond the last checkpoint
+                in.ck_mode = 2;
+                in.last_flip = last_flip;
+                strip_io(0);
                 FastOut ro = o;
-                ro.repaired = false; ro.brow_bad = false;
+                ro.repaired = false; ro.c_out = 0;
                 ro = fast_strip<SEM, PWM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : ALN_FULL_R);
                 __threadfence_block();
-                if (!__any(ro.repaired) || __any(ro.brow_bad)) {          // escalate to a full pass
-                    passes |= __any(ro.brow_bad) ? 0x200000u : 0x300000u;   // diagnostics (bits 20..23): why
-                    break;
-                }
-                passes = (passes & ~0xf0000u) | ((ro.ck_slot + 1u) << 16);  // diagnostics: where the repair re-converged
-                if (ns > 1) { converged = true; break; }                  // the bottom strip, hence z, is untouched
+                if (!__any(ro.repaired)) { failed = true; passes |= 0x300000u; break; }       // no re-convergence (or a stale end-cell candidate)
+                if (ro.c_out != 0) { failed = true; passes |= 0x200000u; break; }            // strip 0's bottom row moved
+                passes = (passes & ~0xf0000u) | ((ro.ck_slot + 1u) << 16);               // diagnostics: where the repair re-converged
+                o = ro;
+                if (ns > 1) { converged = true; break; }                                  // the bottom strip, hence z, is untouched
                 converged = adopt_advice_zdw(in.advice, reinterpret_cast<const uint32_t *>(in.zrow), N, M, lane, last_flip);   // single strip: z may have moved
             }
             if (converged) break;
-            if (!(passes & 0xf00000u)) passes |= last_flip > 512 ? 0x100000u : 0x400000u;
+            if (!(passes & 0xf00000u)) passes |= 0x400000u;
         }
         if ((passes & 0xffu) >= max_passes) break;
     }
     if (!converged) {                                    // strict reference order (exact for every input)
         Wave<int> c;
         c.lane = 0; c.N = N; c.M = M; c.q = in.q; c.t = in.t; c.S = in.S; c.cols = in.cols; c.del = del; c.ext = ext;
-        c.dirw = in.dirw; c.brow = in.brow; c.hmat = nullptr; c.store_dirs = in.store_dirs; c.pwm = in.pwm;
+        c.dirw = in.dirw; c.brow = fs.rows; c.hmat = nullptr; c.store_dirs = in.store_dirs; c.pwm = in.pwm;
         c.bv = 0; c.by = 0; c.bx = 0; c.corner = 0;
         if (lane == 0) serial_fill_impl<int, SEM>(c);
         __threadfence_block();
@@ -663,11 +688,17 @@ void aln_fill_fast_kernel(FillArgs a)
     uint8_t *sc = a.scratch + (uint64_t)wave * a.scratch_stride;
     const uint64_t brow_bytes = ((uint64_t)(a.max_len + 66) * 4 + 63) & ~(uint64_t)63;
     const uint64_t adv_bytes = ((uint64_t)a.max_len + 66 + 63) & ~(uint64_t)63;
-    in.brow = reinterpret_cast<int *>(sc);
-    in.advice = sc + brow_bytes;
-    in.zrow = sc + brow_bytes + adv_bytes;
-    in.ckpt = reinterpret_cast<int *>(sc + brow_bytes + adv_bytes + a.zrow_bytes);
-    in.brow0 = in.ckpt + ALN_CK_SLOTS * 18 * 64;
+    // [boundary rows][advice][bottom-row record][checkpoint sets]
+    FastScratch fs;
+    fs.nrows = a.cascade_rows ? a.cascade_rows : 1u;
+    fs.rows = reinterpret_cast<int *>(sc);
+    fs.row_ints = (uint32_t)(brow_bytes / 4);
+    in.brow_in = fs.rows; in.brow_out = fs.rows;
+    in.advice = sc + (uint64_t)fs.nrows * brow_bytes;
+    in.zrow = in.advice + adv_bytes;
+    fs.ckpt = reinterpret_cast<int *>(in.zrow + a.zrow_bytes);
+    fs.ck_ints = ALN_CK_SLOTS * 18 * 64;
+    in.ckpt = fs.ckpt;
     in.S = S;
     in.cols = a.cols;
     in.prof = smem + ((a.rows * a.cols * 4u + 15u) & ~15u) + (threadIdx.x >> 6) * a.prof_stride;
@@ -684,7 +715,7 @@ void aln_fill_fast_kernel(FillArgs a)
         else if (!pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, in.lane)) skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, in.lane);
         else {
             set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
-            plain = do_pair_fast<SEM, PWM>(in, a, desc, res, (int)a.del, (int)a.ext);
+            plain = do_pair_fast<SEM, PWM>(in, fs, a, desc, res, (int)a.del, (int)a.ext);
         }
         pair_done(a, in.lane, pair, plain);
     }
@@ -735,7 +766,7 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     in.prof = base + s_bytes + qo_bytes + wave * (prof_bytes + 512u);
     in.lds_scratch = ((uint32_t)(uintptr_t)(base + s_bytes + qo_bytes + W * (prof_bytes + 512u)) + 255u) & ~255u;   // 512 B, 256-aligned
     in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
-    in.brow = nullptr; in.brow0 = nullptr; in.ckpt = nullptr;
+    in.brow_in = nullptr; in.brow_out = nullptr; in.ckpt = nullptr;
     in.advice = a.advice; in.zrow = a.zrow;
     in.hazard = a.hazard != 0;
     in.adv_any = a.hazard != 0 && a.pass != 0;
