@@ -497,8 +497,10 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         const char *e = getenv("ALN_TB_OVERLAP");
         const uint32_t reserve = e ? (uint32_t)atoi(e) : 0u;
         const bool off = e && reserve == 0;
+        // (only where the fill is long enough to hide anything behind: the walk waves, their 30 us head start and the
+        // write-through stores cost a batch of 10 000 read pairs -- 0.3 ms of fill -- 40 % of its time)
         k.overlap = allow_overlap && !off && c.fast && c.is_int && c.want_tb && c.store_dirs && reserve < resident &&
-                    k.n_small >= 4096 && wg_needed >= resident;
+                    k.n_small >= 4096 && wg_needed >= resident && (k.cells >= 2000000000ull || getenv("ALN_TB_OVERLAP_ANY"));
         k.counter_bytes = 256;
         if (k.overlap) {
             k.grid = resident - reserve;

@@ -636,9 +636,11 @@ def test_single_pair_traceback_outside_the_exit_map_band(orc, blosum62, sem):
         assert res.flags & 2 and res.aln_len > 2900
 
 
-def test_overlapped_traceback_batch(orc, blosum62):
-    """A batch large enough (>= 4096 pairs) for the walk kernel to run beside the fill kernel: every summary and both
-    strings against the oracle, and a second run of the same staged batch (new epoch of the "walked" marks) repeats them."""
+def test_overlapped_traceback_batch(orc, blosum62, monkeypatch):
+    """A batch large enough (>= 4096 pairs; ALN_TB_OVERLAP_ANY lifts the 2e9-cell floor) for the walk kernel to run beside the
+    fill kernel: every summary and both strings against the oracle, and a second run of the same staged batch (new epoch of
+    the "walked" marks) repeats them."""
+    monkeypatch.setenv("ALN_TB_OVERLAP_ANY", "1")
     b = workloads.c5_batch(n_pairs=5000, lo=30, hi=260)
     got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
     from aligner_amd.batch import StagedBatch
@@ -657,6 +659,7 @@ def test_overlapped_traceback_batch(orc, blosum62):
 def test_overlapped_traceback_gives_up_cleanly(orc, blosum62, monkeypatch):
     """The walk kernel that runs beside the fill may give up on a wait (ALN_TB_WAIT_US=0: at the first entry that is not
     there yet); the sweep after the fill walks what it left, and the results do not change."""
+    monkeypatch.setenv("ALN_TB_OVERLAP_ANY", "1")
     monkeypatch.setenv("ALN_TB_WAIT_US", "0")
     b = workloads.c5_batch(n_pairs=4500, lo=30, hi=200)
     _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
@@ -664,10 +667,11 @@ def test_overlapped_traceback_gives_up_cleanly(orc, blosum62, monkeypatch):
     _check_batch(orc, b, _ffi.CORE_LOCAL, 11, 2, blosum62)
 
 
-def test_pwm_window_batch_with_overlapped_traceback(orc):
+def test_pwm_window_batch_with_overlapped_traceback(orc, monkeypatch):
     """5000 short windows against one PWM: enough pairs for the walk kernel to run beside the fill (PWM tag strings sit
     behind the u32 column numbers, and a window without a positive cell has no walk at all)."""
     from aligner_amd.pwm import align_windows
+    monkeypatch.setenv("ALN_TB_OVERLAP_ANY", "1")
     rng = np.random.default_rng(4242)
     pwm = rng.integers(-2, 3, (4, 48)).astype(np.float64)
     chrom = rng.integers(0, 4, 60000).astype(np.uint8)
