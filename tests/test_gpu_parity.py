@@ -91,7 +91,9 @@ def test_cli_plumbing_book_example(blosum62):
 # ---------------------------------------------------------------- differential tests vs the oracle
 @pytest.mark.parametrize("sem", SEMS)
 @pytest.mark.parametrize("shape", [(1, 1), (1, 7), (9, 1), (10, 7), (64, 64), (65, 63), (130, 129), (257, 70),
-                                   (200, 513), (90, 1030)])
+                                   (200, 513), (90, 1030),
+                                   # last strips of every height class: R = 3, 4, 5, 6, 7, 8 rows per lane (aln_pick_r)
+                                   (110, 190), (75, 250), (100, 300), (120, 350), (90, 420), (70, 500), (150, 812), (80, 940)])
 def test_random_protein_full_matrix(orc, blosum62, sem, shape):
     """Full H and D matrices from the generic integer kernels (the H dump routes there), summary + directions +
     strings from the fast (query-profile) integer kernels."""
