@@ -7,7 +7,9 @@
 //   T' = (key & ~3) | 2          Beginning (H' == 0, local, enums.rs:37) is tag 3; the legacy clamp at zero
 //                                (aligner_core.rs:210) is max(key, 3).
 // Substitution scores come from a per-strip query profile in LDS, P[c][row] = 4*S[t[row]][c] - 2 as int8, row-contiguous
-// per code: one ds_read of R bytes per step feeds the lane's R cells (SDWA byte adds), conflict-free by construction.
+// per code: one ds_read of R bytes per step feeds the lane's R cells (SDWA byte adds).  Not conflict-free: at a step the
+// lanes read the rows of up to 24 different codes, 512 B apart (measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.39);
+// LDS instructions are 1.4 % of the VALU count, so it does not bind.
 // The query code flows down the lanes with the same DPP wave_shr:1 that carries the boundary cell.
 // Local end cell: per row one packed register  (T' << 11) | f(step)  updated with one v_lshl_add per cell and one v_max3
 // per two steps, folded every 2048 steps with the exact tie rule (first in row-major order: core; last in column-major
