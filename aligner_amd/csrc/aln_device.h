@@ -104,6 +104,14 @@ struct SingleArgs {
     uint32_t store_dirs;
     uint32_t test_drop;       // fault injection (env ALN_TEST_DROP_STRIP = s + 1): strip s never runs -- the run must end
                               // poisoned (ALN_ERR_DEVICE) within the polls' bounds, not hang
+    // Localized repair of the row-1 hazard (see aln_single_repair_finalize_kernel): when pass 0's advice turns out wrong in the
+    // leading columns only, the first rep_S strips re-run their leading columns -- strip s up to step rep_K + 64 (rep_S - 1 - s),
+    // where pass 0 saved its lane state -- instead of the whole pipeline running a second time.
+    int *ckpt;                // lane state of strips < rep_S at their stop steps (18 x 64 ints per strip), saved by pass 0
+    uint32_t *rgranules;      // scratch granule rows of the repair run (rep_S rows of gstride), zeroed by the kernel that arms it
+    int32_t *rcand;           // per repaired strip {new prefix candidate (bv, by, bx), old prefix candidate (bv, by, bx), converged, 0}
+    uint32_t rep_S, rep_K;    // strips re-run (0: this pair is never repaired), stop step of the last of them
+    uint32_t mode;            // 0 = a full pass (`pass`, gated by ctrl[1 + pass]); 1 = the repair run (gated by ctrl[8])
 };
 
 // strip 0 of a hazard pair checkpoints its lane state at steps max(16, one quad), then doubling, up to 512

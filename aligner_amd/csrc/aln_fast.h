@@ -137,6 +137,8 @@ struct FastIn {
     bool wt_dirs;             // batch kernels: direction quads are stored write-through (a walk kernel on another XCD reads them while this kernel runs)
     bool pwm;                 // position-weight-matrix scoring (batch kernels only)
     const uint32_t *pwm_words;// per column: int8 scores 4*s - 2 of residues 0..3
+    uint32_t ck_stop;         // single-pair kernel: the step at which pass 0 saves the strip's lane state (ck_mode 1) / the repair run
+                              // stops and compares (ck_mode 2); 0 = none
     int ck_mode;              // 0 plain, 1 save checkpoints, 2 repair
     uint32_t last_flip;       // repair: last column whose input to this strip (row-1 advice, or the row above) differs from the checkpointed pass
     uint16_t *qo_pad;         // single-pair kernel: LDS, q[x] * 64R at index x + 63, zeros elsewhere (N + 192 entries)
@@ -587,6 +589,24 @@ struct FastStrip {
         }
     }
 
+    // the same for the tracker registers a checkpoint saved (the candidates of the prefix the checkpointed pass computed)
+    __device__ __forceinline__ void fold_saved(FastOut &o, uint32_t slot)
+    {
+        const int *base = in.ckpt + slot * (18 * 64) + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int v = base[(2 * r + 1) * 64];
+            const uint32_t y = yb + 1 + r;
+            if (v != INT_MIN && y <= in.M) {
+                const int t = v >> 11;
+                const uint32_t kk = (uint32_t)v & 2047u;
+                const uint32_t k = (SEM == ALN_CORE_LOCAL) ? 2047u - kk : kk;
+                const uint32_t x = k - (uint32_t)lane + 1;
+                if (o.bx == 0 || better_i<SEM>(t, y, x, o.bv, o.by, o.bx)) { o.bv = t; o.by = y; o.bx = x; }
+            }
+        }
+    }
+
     // Lane state at a block boundary (direction word flushed, input chunks about to be reloaded): everything the
     // rest of the strip depends on besides the inputs.  save = store it; !save = "is the DP state identical to the stored
     // one".  The end-cell tracker's registers need not re-converge: `tracker` says whether they differ from the stored
@@ -691,9 +711,11 @@ struct FastStrip {
         if (ASMPATH && GLOBAL_ASM && FIRST && kb_steady1 * SPB >= N && kb_steady1 >= kb_steady0 + 4u) kb_steady1 -= 4u;
         // Segment ends: the 2048-step chunks of the end-cell tracker and, for strip 0 of a hazard pair, the
         // checkpoint steps 64, 128, 256, 512.
-        const bool ckmode = FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0;
+        // (single-pair kernel: ONE checkpoint, at in.ck_stop -- saved by pass 0, the end of the repair run)
+        const bool cks = SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0 && in.ck_stop != 0;
+        const bool ckmode = cks || (FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0);
         // checkpoints sit on quad boundaries: the first at max(16, one quad of 4 * SPB steps), then doubling up to 512
-        uint32_t next_ck = ckmode ? ((ALN_CK_FIRST + 4u * SPB - 1u) / (4u * SPB)) * (4u * SPB) : 0xffffffffu, slot = 0, chunk_base = 0;
+        uint32_t next_ck = cks ? in.ck_stop : ckmode ? ((ALN_CK_FIRST + 4u * SPB - 1u) / (4u * SPB)) * (4u * SPB) : 0xffffffffu, slot = 0, chunk_base = 0;
         chunk0 = 0;
         uint32_t kb = 0;
         while (kb < nkb) {
@@ -733,7 +755,17 @@ struct FastStrip {
             }
             for (; kb < e1; kb += 4) quad<false>(dirq, kb);
             for (; kb < seg_end; kb += 4) quad<true>(dirq, kb);
-            if (ckmode && kb < nkb && kb * SPB == next_ck) {
+            if (cks && kb < nkb && kb * SPB == next_ck) {
+                bool tracker = false, stale = false;
+                if (in.ck_mode == 1) { checkpoint(0, true, o, tracker, stale); next_ck = 0xffffffffu; }
+                else {
+                    // the repair run ends here: has every lane rejoined the state pass 0 had at this step?  (The tracker
+                    // registers hold the re-run prefix's candidates; the kernel folds them and pass 0's saved ones.)
+                    o.repaired = __all(checkpoint(0, false, o, tracker, stale));
+                    o.aborted = o.aborted || aborted;
+                    return o;
+                }
+            } else if (ckmode && kb < nkb && kb * SPB == next_ck) {
                 bool tracker = false, stale = false;
                 if (in.ck_mode == 1) checkpoint(slot, true, o, tracker, stale);
                 else if (__all(checkpoint(slot, false, o, tracker, stale)) && in.last_flip <= next_ck) {

@@ -53,6 +53,7 @@ extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N
 extern "C" void aln_launch_traceback_expand_single(const TraceArgs *a, uint32_t pair, hipStream_t s);
 extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_serial, hipStream_t s);
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s);
+extern "C" void aln_launch_single_repair(const SingleArgs *a, uint32_t N, hipStream_t s);
 extern "C" uint32_t aln_single_lds_bytes(uint32_t rows, uint32_t cols, uint32_t R, uint32_t N, uint32_t W);
 extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, uint32_t pair, int semantics, uint8_t *out,
                                   uint64_t cells, hipStream_t s);
@@ -129,7 +130,7 @@ static void pin_free(PinBuf &b)
 struct Slot {
     bool pooled = true;       // pool slots keep some slack when they grow; a staged batch's private slot is sized exactly
     DevBuf seqs, descs, order, counter, walked, dirs, results, tb, tags, scratch, matrix, pwm_words, hmat;
-    DevBuf granules, advice1, cand, ctrl, tbmap, unpack;
+    DevBuf granules, advice1, cand, ctrl, tbmap, unpack, repair;
     PinBuf h_meta;            // descs + order + matrix + pwm words (small, truly asynchronous H2D)
     PinBuf h_in, h_out;       // fallback staging: sequences gathered from scattered offsets / strings for a foreign tb layout
     hipStream_t stream = nullptr;
@@ -170,7 +171,7 @@ static void slot_destroy(Slot *s)
 {
     if (!s) return;
     DevBuf *d[] = {&s->seqs, &s->descs, &s->order, &s->counter, &s->walked, &s->dirs, &s->results, &s->tb, &s->tags, &s->scratch,
-                   &s->matrix, &s->pwm_words, &s->hmat, &s->granules, &s->advice1, &s->cand, &s->ctrl, &s->tbmap, &s->unpack};
+                   &s->matrix, &s->pwm_words, &s->hmat, &s->granules, &s->advice1, &s->cand, &s->ctrl, &s->tbmap, &s->unpack, &s->repair};
     for (DevBuf *b : d) dev_free(*b);
     pin_free(s->h_meta); pin_free(s->h_in); pin_free(s->h_out);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -367,7 +368,7 @@ struct Chunk {
     size_t n_small = 0;
     uint64_t cells = 0, max_cells = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, hmat_elems = 0;
     uint32_t max_len = 1, grid = 1, zrow_bytes = 0, lds_bytes = 0, prof_stride = 0, tb_waves = 0, single_max_n = 0, cascade_rows = 1;
-    uint64_t scratch_stride = 0, granule_bytes = 0, tbmap_entries = 0;
+    uint64_t scratch_stride = 0, granule_bytes = 0, tbmap_entries = 0, granule_stride_max = 0;
     size_t counter_bytes = 256;
     bool overlap = false;             // walk waves beside the fill (in-kernel overlapped traceback)
     // sequences: either one contiguous span of the caller's buffer, or gathered pair by pair into pinned staging
@@ -443,6 +444,7 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
                 k.single_pairs.push_back((uint32_t)i);
                 k.single_r.push_back(R);
                 const uint64_t gstride = ((uint64_t)d.N + 64 + 63) & ~63ull;
+                k.granule_stride_max = std::max(k.granule_stride_max, gstride);
                 k.granule_bytes = std::max<uint64_t>(k.granule_bytes, std::max<uint64_t>((uint64_t)ns * gstride * 4, 4ull * (d.M + 2)));
                 k.single_max_n = std::max(k.single_max_n, std::max(d.N, ns));
                 k.tbmap_entries = std::max<uint64_t>(k.tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
@@ -574,6 +576,8 @@ static int slot_ensure(Slot &s, const Call &c, const Chunk &k, const Need *need 
         ENS(cand, 16ull * (k.single_max_n + 64));
         ENS(ctrl, 256);
         ENS(tbmap, k.tbmap_entries * 16);
+        // localized repair of the single-pair route: up to 8 strips' scratch granule rows, checkpoints, candidates
+        ENS(repair, 8ull * (k.granule_stride_max * 4 + 18 * 64 * 4 + 32) + 256);
     }
 #undef ENS
     // pinned staging of the small tables: descs | order | matrix | pwm words
@@ -706,6 +710,17 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
         sa.store_dirs = c.store_dirs ? 1u : 0u;
         { const char *td = getenv("ALN_TEST_DROP_STRIP"); sa.test_drop = td ? (uint32_t)atoi(td) : 0u; }
         sa.max_passes = sa.hazard ? std::min<uint32_t>(c.p.max_passes ? c.p.max_passes : 4u, 12u) : 1u;
+        // Localized repair (hazard pairs): when pass 0's advice is wrong in leading columns only, the first rep_S strips re-run
+        // their leading columns (strip s up to step rep_K + 64 (rep_S - 1 - s)) instead of the whole pipeline running again.
+        sa.rep_S = 0; sa.rep_K = 0; sa.mode = 0;
+        {
+            const uint32_t S = sa.R >= 2 ? 4u : 8u, K = 256u;
+            if (sa.hazard && !getenv("ALN_NO_SINGLE_REPAIR") && sa.R <= 2 && sa.ns > S && d.N >= K + 64u * S + 128u) { sa.rep_S = S; sa.rep_K = K; }
+            uint8_t *rb = s.repair.as<uint8_t>();
+            sa.rgranules = reinterpret_cast<uint32_t *>(rb);
+            sa.ckpt = reinterpret_cast<int *>(rb + 8ull * k.granule_stride_max * 4);
+            sa.rcand = reinterpret_cast<int32_t *>(rb + 8ull * k.granule_stride_max * 4 + 8ull * 18 * 64 * 4);
+        }
         aln_launch_single_init(&sa, (uint32_t)single_advice_bytes(d.N), st);
         // the granule rows must read "not yet produced" before a pass: one memset here, later passes are zeroed by the
         // finalize kernel that arms them
@@ -714,6 +729,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
             sa.pass = pass;
             aln_launch_single(&sa, d.N, pass + 1 == sa.max_passes ? 1 : 0, st);
             launches++;
+            if (pass == 0 && sa.rep_S) aln_launch_single_repair(&sa, d.N, st);      // exits at once unless pass 0 armed it
         }
         HIPCHK(hipGetLastError());
     }

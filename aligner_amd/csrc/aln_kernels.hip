@@ -732,7 +732,9 @@ void aln_fill_fast_kernel(FillArgs a)
 template <int SEM, int R, int W>
 __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
 {
-    if (__hip_atomic_load(a.ctrl + 1 + a.pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const bool repair = a.mode == 1;             // the repair run: the first rep_S strips, their leading columns, gated by ctrl[8]
+    if (__hip_atomic_load(a.ctrl + (repair ? 8u : 1u + a.pass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    if (repair && blockIdx.x * W >= a.rep_S) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t RING_BYTES = 4u * ALN_RING;
     unsigned char *base = smem + (W - 1) * RING_BYTES;
@@ -772,10 +774,17 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     in.adv_any = a.hazard != 0 && a.pass != 0;
     in.store_dirs = a.store_dirs != 0;
     in.pwm = false; in.pwm_words = nullptr;
-    in.ck_mode = 0; in.last_flip = 0;
+    in.ck_mode = 0; in.last_flip = 0; in.ck_stop = 0;
     const bool last = strip + 1 == a.ns;
-    in.gin = a.granules + (uint64_t)(strip ? strip - 1 : 0) * a.gstride;
-    in.gout = a.granules + (uint64_t)strip * a.gstride;
+    uint32_t *gbase = repair ? a.rgranules : a.granules;
+    in.gin = gbase + (uint64_t)(strip ? strip - 1 : 0) * a.gstride;
+    in.gout = gbase + (uint64_t)strip * a.gstride;
+    if (SEM == ALN_CORE_LOCAL && a.rep_S != 0 && strip < a.rep_S && (repair || a.pass == 0)) {
+        in.ckpt = a.ckpt + (size_t)strip * (18 * 64);
+        in.ck_stop = a.rep_K + 64u * (a.rep_S - 1u - strip);
+        in.ck_mode = repair ? 2 : 1;
+    }
+    if (repair) { if (strip >= a.rep_S) return; in.adv_any = true; }
     in.ring_in = (W > 1 && wave > 0) ? reinterpret_cast<uint32_t *>(smem + (wave - 1) * RING_BYTES) : nullptr;
     in.ring_out = (W > 1 && wave + 1 < W && !last) ? reinterpret_cast<uint32_t *>(smem + wave * RING_BYTES) : nullptr;
     in.abort_flag = a.ctrl;
@@ -783,13 +792,32 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0;
     in.qo_pad = qo_pad;
     in.bring = reinterpret_cast<int *>(in.prof + prof_bytes);
+    // (after a repair run: the candidates of the re-run prefix and of the prefix pass 0 had computed, for the merge)
+    auto run = [&](auto &fs) {
+        o = fs.run(o);
+        if (repair) {
+            FastOut nw = o, od = o;
+            nw.bv = INT_MIN; nw.by = 0; nw.bx = 0; od.bv = INT_MIN; od.by = 0; od.bx = 0;
+            fs.fold(nw, 0);
+            fs.fold_saved(od, 0);
+            reduce_best<SEM>(nw);
+            reduce_best<SEM>(od);
+            if (in.lane == 0) {
+                int32_t *c = a.rcand + 8 * strip;
+                c[0] = nw.bv; c[1] = (int32_t)nw.by; c[2] = (int32_t)nw.bx;
+                c[3] = od.bv; c[4] = (int32_t)od.by; c[5] = (int32_t)od.bx;
+                c[6] = (o.repaired && !o.aborted) ? 1 : 0; c[7] = 0;
+            }
+        }
+    };
     if (strip == 0) {
-        if (last) { FastStrip<SEM, R, true, true, true> fs(in, strip); o = fs.run(o); }
-        else { FastStrip<SEM, R, true, true, false> fs(in, strip); o = fs.run(o); }
+        if (last) { FastStrip<SEM, R, true, true, true> fs(in, strip); run(fs); }
+        else { FastStrip<SEM, R, true, true, false> fs(in, strip); run(fs); }
     } else {
-        if (last) { FastStrip<SEM, R, true, false, true> fs(in, strip); o = fs.run(o); }
-        else { FastStrip<SEM, R, true, false, false> fs(in, strip); o = fs.run(o); }
+        if (last) { FastStrip<SEM, R, true, false, true> fs(in, strip); run(fs); }
+        else { FastStrip<SEM, R, true, false, false> fs(in, strip); run(fs); }
     }
+    if (repair) return;
     if (is_local<SEM>()) reduce_best<SEM>(o);
     if (in.lane == 0) {
         int32_t *c = a.cand + 4 * strip;
@@ -820,11 +848,26 @@ __global__ __launch_bounds__(1024) void aln_single_finalize_kernel(SingleArgs a)
         return ((zdw[k / spb] >> aln_dir_bitpos(k, rb, lb, N, (int)a.R)) & 3u) == 3u ? 1 : 0;
     };
     int mismatch = 0;
-    if (a.hazard) for (uint32_t x = 2 + tid; x <= N; x += blockDim.x) mismatch |= (a.advice[x] != bottom_zero(x - 1));
+    __shared__ uint32_t far_flip;                  // does the advice change beyond the columns a repair run can absorb?
+    if (tid == 0) far_flip = 0;
+    __syncthreads();
+    if (a.hazard) for (uint32_t x = 2 + tid; x <= N; x += blockDim.x)
+        if (a.advice[x] != bottom_zero(x - 1)) { mismatch = 1; if (x > a.rep_K / 2u) far_flip = 1; }
     const bool again = __syncthreads_or(mismatch) != 0;
     const bool aborted = a.ctrl[0] != 0;
     if (again && !aborted) {
         for (uint32_t x = 2 + tid; x <= N; x += blockDim.x) a.advice[x] = bottom_zero(x - 1);
+        if (a.pass == 0 && a.rep_S != 0 && far_flip == 0 && a.max_passes >= 2) {
+            // Only leading columns of row 1 change: arm the repair run instead of a second pass of the whole pipeline.
+            // Its granule rows must read "not yet produced".
+            uint4 *g = reinterpret_cast<uint4 *>(a.rgranules);
+            const uint64_t n16 = (uint64_t)a.rep_S * a.gstride / 4u;
+            for (uint64_t i = tid; i < n16; i += blockDim.x) g[i] = make_uint4(0, 0, 0, 0);
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) a.ctrl[8] = 1;
+            return;
+        }
         if (a.pass + 1 < a.max_passes) {
             uint4 *g = reinterpret_cast<uint4 *>(a.granules);       // the next pass needs "not yet produced" everywhere
             const uint64_t n16 = (uint64_t)a.ns * a.gstride / 4u;   // gstride is a multiple of 64
@@ -851,6 +894,62 @@ __global__ __launch_bounds__(1024) void aln_single_finalize_kernel(SingleArgs a)
         desc.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
         write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)corner, N, M, a.pass + 1, 1u | 2u);
         if (aborted) res.status = ALN_ERR_DEVICE;
+    }
+}
+
+// After the repair run (gated by ctrl[8]).  The repair is valid iff every re-run strip rejoined its checkpointed lane state,
+// the bottom row of the last of them -- what the first strip NOT re-run reads -- came out as pass 0 had it, and no strip's
+// end-cell candidate stems from a prefix cell that the re-run no longer produces.  Then the result is published with the
+// re-run prefixes' candidates merged in (the directions of those columns have been rewritten in place); otherwise pass 1 of
+// the whole pipeline is armed, as the finalize kernel would have done.
+template <int SEM>
+__global__ __launch_bounds__(1024) void aln_single_repair_finalize_kernel(SingleArgs a)
+{
+    if (__hip_atomic_load(a.ctrl + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const uint32_t tid = threadIdx.x;
+    const int lane = (int)(tid & 63u);
+    PairDesc &desc = a.descs[a.pair];
+    aln_pair_result &res = a.results[a.pair];
+    const uint32_t S = a.rep_S;
+    int bad = 0;
+    if (tid < S) {
+        const int32_t *c = a.rcand + 8 * tid, *w = a.cand + 4 * tid;
+        if (c[6] == 0) bad = 1;
+        // pass 0's winner of this strip came from the old prefix, and the new prefix does not have that cell any more
+        const bool old_leads = c[5] != 0 && c[3] == w[0] && c[4] == w[1] && c[5] == w[2];
+        const bool same = c[0] == c[3] && c[1] == c[4] && c[2] == c[5];
+        if (old_leads && !same) bad = 1;
+    }
+    // bottom row of strip S - 1, columns the repair run recomputed (its last strip stopped at step rep_K: lane 63 at column rep_K - 63)
+    const uint32_t *gn = a.rgranules + (uint64_t)(S - 1) * a.gstride, *go = a.granules + (uint64_t)(S - 1) * a.gstride;
+    for (uint32_t x = tid; x + 63u < a.rep_K && x < desc.N; x += blockDim.x) if (gn[x] != go[x]) bad = 1;
+    const bool failed = __syncthreads_or(bad) != 0 || a.ctrl[0] != 0;
+    if (failed) {
+        uint4 *g = reinterpret_cast<uint4 *>(a.granules);           // pass 1 needs "not yet produced" everywhere
+        const uint64_t n16 = (uint64_t)a.ns * a.gstride / 4u;
+        for (uint64_t i = tid; i < n16; i += blockDim.x) g[i] = make_uint4(0, 0, 0, 0);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) { a.ctrl[8] = 0; a.ctrl[2] = 1; }
+        return;
+    }
+    if (tid >= 64) return;
+    FastOut o;
+    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0;
+    for (uint32_t s = lane; s < a.ns; s += 64) {
+        const int32_t *c = a.cand + 4 * s;
+        if (c[2] != 0 && (o.bx == 0 || better_i<SEM>(c[0], (uint32_t)c[1], (uint32_t)c[2], o.bv, o.by, o.bx))) { o.bv = c[0]; o.by = c[1]; o.bx = c[2]; }
+        if (s < S) {
+            const int32_t *n = a.rcand + 8 * s;
+            if (n[2] != 0 && (o.bx == 0 || better_i<SEM>(n[0], (uint32_t)n[1], (uint32_t)n[2], o.bv, o.by, o.bx))) { o.bv = n[0]; o.by = n[1]; o.bx = n[2]; }
+        }
+    }
+    reduce_best<SEM>(o);
+    if (lane == 0) {
+        const int corner = a.cand[4 * (a.ns - 1) + 3] >> 2;
+        desc.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
+        write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)corner, desc.N, desc.M, 1u | 0x100u, 1u | 2u);
+        a.ctrl[8] = 0;
     }
 }
 
@@ -1530,6 +1629,30 @@ extern "C" void aln_launch_validate(const uint8_t *seqs, PairDesc *descs, uint32
                                     hipStream_t s)
 {
     if (n_pairs) hipLaunchKernelGGL(aln_validate_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, s, seqs, descs, n_pairs, rows, cols, pwm ? 1u : 0u);
+}
+// the repair run + its finalize (both exit at once unless pass 0's finalize armed ctrl[8]); core local only
+extern "C" void aln_launch_single_repair(const SingleArgs *a0, uint32_t N, hipStream_t s)
+{
+    if (a0->rep_S == 0 || a0->semantics != ALN_CORE_LOCAL) return;
+    SingleArgs a = *a0;
+    a.mode = 1;
+    const uint32_t W = aln_single_waves(a.semantics, a.R, a.rows, a.cols, N, a.ns);
+    const uint32_t lds_bytes = aln_single_lds_bytes(a.rows, a.cols, a.R, N, W);
+    const dim3 g((a.rep_S + W - 1) / W), b(64 * W);
+#define ALN_REPAIR_LAUNCH(RR, WW)                                                                              \
+    do {                                                                                                       \
+        auto kern = aln_fill_single_kernel<ALN_CORE_LOCAL, RR, WW>;                                            \
+        if (lds_bytes > 64u * 1024u)                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL(kern, g, b, lds_bytes, s, a);                                                       \
+    } while (0)
+    if (W == 4) { if (a.R == 1) ALN_REPAIR_LAUNCH(1, 4); else ALN_REPAIR_LAUNCH(2, 4); }
+    else if (a.R == 1) ALN_REPAIR_LAUNCH(1, 1);
+    else if (a.R == 2) ALN_REPAIR_LAUNCH(2, 1);
+    else if (a.R == 4) ALN_REPAIR_LAUNCH(4, 1);
+    else ALN_REPAIR_LAUNCH(8, 1);
+#undef ALN_REPAIR_LAUNCH
+    hipLaunchKernelGGL((aln_single_repair_finalize_kernel<ALN_CORE_LOCAL>), dim3(1), dim3(1024), 0, s, a);
 }
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s)
 {

@@ -253,6 +253,30 @@ def test_c4_uniform_pair_the_bench_times(orc, blosum62):
     assert res.score == 8806.0 and res.flags & 2
 
 
+def test_single_pair_route_repairs_the_row1_hazard_locally(orc, blosum62, monkeypatch):
+    """About half of all large pairs turn out to need a different row-1 advice in a few leading columns (core local, del != ext).
+    The strip pipeline then re-runs the leading columns of its first strips (passes bit 8) instead of running a second time:
+    summaries and strings against the oracle over several seeds, uniform and homolog, R = 1 and R = 2, with the full direction
+    matrix for the smaller ones; the same pairs with the repair switched off (full second pass) give the same answers."""
+    seen_repair = 0
+    for seed in range(10):
+        rng = np.random.default_rng(900 + seed)
+        N, M = ((2200, 1500) if seed % 2 else (3000, 4300))            # R = 1 (16+ strips) / R = 2
+        q = rng.integers(0, 20, N).astype(np.uint8)
+        t = workloads.mutate(q, 50 + seed, 20, 0.10, 0.02, out_len=M) if seed % 3 == 0 else rng.integers(0, 20, M).astype(np.uint8)
+        res = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=(seed % 2 == 1), directions_only=True)
+        assert res.flags & 2
+        repaired = bool(res.passes & 0x100)
+        seen_repair += repaired
+        assert (res.passes & 0x7f) == 1 or not repaired
+        if repaired:
+            monkeypatch.setenv("ALN_NO_SINGLE_REPAIR", "1")
+            again = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=False)
+            monkeypatch.delenv("ALN_NO_SINGLE_REPAIR")
+            assert (again.passes & 0x7f) == 2 and again.score == res.score
+    assert seen_repair >= 2, seen_repair
+
+
 def test_long_pairs_beyond_the_old_column_limit(orc, blosum62):
     """The single-pair route stages the whole query's profile offsets in LDS.  Up to r01 the host refused it above a 64 KiB
     budget (N ~ 29 400 columns) and such a pair fell to the one-wave batch kernel; a workgroup now opts in to the CU's whole
