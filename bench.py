@@ -376,6 +376,30 @@ def main():
                                    "fill_only_gcups": round(one.cells / tm["fill_ms"] / 1e6, 3),
                                    "score": float(r1["score"]), "status": int(r1["status"])}
             sp.close()
+            # the same shape over other inputs: about half of all large pairs need their row-1 advice corrected in a few leading
+            # columns, which the strip pipeline repairs locally (r01: a second run of the whole pipeline, ~37 GCUPS)
+            rates, repaired, two_pass = [], 0, 0
+            for kind in ("uniform", "homolog"):
+                for seed in range(4):
+                    qq = workloads.random_codes(workloads.SEED_C4 + 31 * seed, 10000, 20)
+                    tt = workloads.mutate(qq, seed + 5, 20, 0.10, 0.02) if kind == "homolog" else workloads.random_codes(77 + seed, 10000, 20)
+                    ob = PairBatch.from_pairs([(qq, tt)])
+                    sv = StagedBatch(ob, _ffi.CORE_LOCAL, 11, 2, S, device=local_rank, outputs=outs)
+                    sv.run(); sv.sync()
+                    sv.enable_timing(True)
+                    for _ in range(3):
+                        sv.run()
+                    sv.sync()
+                    tv = sv.timing()
+                    rv = sv.fetch(want_traceback=False).results[0]
+                    sv.close()
+                    rates.append(ob.cells / (tv["fill_ms"] + tv["traceback_ms"]) / 1e6)
+                    repaired += bool(int(rv["passes"]) & 0x100)
+                    two_pass += (int(rv["passes"]) & 0x7f) > 1
+            line["single_pair"]["other_inputs"] = {
+                "what": "4 uniform-random + 4 homolog (10 % substitutions, 2 % indels) 10000 x ~10000 pairs, device fill + traceback",
+                "gcups_min": round(min(rates), 2), "gcups_median": round(sorted(rates)[len(rates) // 2], 2),
+                "locally_repaired": repaired, "second_full_pass": two_pass}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, S, res)
     if rank == 0:
