@@ -649,7 +649,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     (void)ctx;
     if (fill_launches) *fill_launches = 0;
     if (k.n == 0) return ALN_OK;
-    HIPCHK(hipMemsetAsync(s.counter.p, 0, k.counter_bytes, st));
+    if (k.n_small) HIPCHK(hipMemsetAsync(s.counter.p, 0, k.counter_bytes, st));     // the batch kernel's work queue
     // residue codes outside the matrix: the batch fill kernels check the pairs they take; the single-pair route reads the status
     // from the descriptor, so its pairs are checked by a kernel of their own in front
     if (!k.single_pairs.empty())
@@ -709,6 +709,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
         sa.hazard = (sa.semantics == ALN_CORE_LOCAL && sa.del != sa.ext && d.N >= 2) ? 1u : 0u;
         sa.store_dirs = c.store_dirs ? 1u : 0u;
         { const char *td = getenv("ALN_TEST_DROP_STRIP"); sa.test_drop = td ? (uint32_t)atoi(td) : 0u; }
+        if (getenv("ALN_TEST_FAIL_REPAIR")) sa.test_drop = 0xffffffffu;      // the repair run is declared failed (tests)
         sa.max_passes = sa.hazard ? std::min<uint32_t>(c.p.max_passes ? c.p.max_passes : 4u, 12u) : 1u;
         // Localized repair (hazard pairs): when pass 0's advice is wrong in leading columns only, the first rep_S strips re-run
         // their leading columns (strip s up to step rep_K + 64 (rep_S - 1 - s)) instead of the whole pipeline running again.
@@ -737,7 +738,10 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     if (s.ev_fill) HIPCHK(hipEventRecord(s.ev_fill, st));
     if (c.want_tb && c.store_dirs) {
         if (overlap) HIPCHK(hipStreamWaitEvent(st, s.ev_join, 0));
-        aln_launch_traceback(&ta, st);      // every pair except those in the uniform-R layout (handled below)
+        // every pair except those in the uniform-R layout (handled below); pairs the single-pair route hands to the strict-order
+        // kernel (row-major layout) are walked by these two as well
+        const bool batch_tb = k.n_small != 0 || c.semantics == ALN_CORE_LOCAL;
+        if (batch_tb) aln_launch_traceback(&ta, st);
         for (size_t j = 0; j < k.single_pairs.size(); ++j) {
             const PairDesc &d = k.descs[k.single_pairs[j]];
             TraceSingleArgs tsa{};
@@ -749,7 +753,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
             aln_launch_traceback_single(&tsa, d.N, st);
             aln_launch_traceback_expand_single(&ta, tsa.pair, st);
         }
-        aln_launch_traceback_expand(&ta, st);
+        if (batch_tb) aln_launch_traceback_expand(&ta, st);
         HIPCHK(hipGetLastError());
     }
     if (ev) HIPCHK(hipEventRecord(ev[2], st));

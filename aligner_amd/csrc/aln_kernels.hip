@@ -923,7 +923,8 @@ __global__ __launch_bounds__(1024) void aln_single_repair_finalize_kernel(Single
     // bottom row of strip S - 1, columns the repair run recomputed (its last strip stopped at step rep_K: lane 63 at column rep_K - 63)
     const uint32_t *gn = a.rgranules + (uint64_t)(S - 1) * a.gstride, *go = a.granules + (uint64_t)(S - 1) * a.gstride;
     for (uint32_t x = tid; x + 63u < a.rep_K && x < desc.N; x += blockDim.x) if (gn[x] != go[x]) bad = 1;
-    const bool failed = __syncthreads_or(bad) != 0 || a.ctrl[0] != 0;
+    // (test_drop == ~0: fault injection, the repair is declared failed -- pass 1 must then run and give the same answer)
+    const bool failed = __syncthreads_or(bad) != 0 || a.ctrl[0] != 0 || a.test_drop == 0xffffffffu;
     if (failed) {
         uint4 *g = reinterpret_cast<uint4 *>(a.granules);           // pass 1 needs "not yet produced" everywhere
         const uint64_t n16 = (uint64_t)a.ns * a.gstride / 4u;

@@ -274,6 +274,11 @@ def test_single_pair_route_repairs_the_row1_hazard_locally(orc, blosum62, monkey
             again = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=False)
             monkeypatch.delenv("ALN_NO_SINGLE_REPAIR")
             assert (again.passes & 0x7f) == 2 and again.score == res.score
+            # a repair run that is declared failed arms pass 1 (device-side): same answer after two passes
+            monkeypatch.setenv("ALN_TEST_FAIL_REPAIR", "1")
+            again = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, blosum62, full=False)
+            monkeypatch.delenv("ALN_TEST_FAIL_REPAIR")
+            assert (again.passes & 0x7f) == 2 and not (again.passes & 0x100)
     assert seen_repair >= 2, seen_repair
 
 
