@@ -79,16 +79,30 @@ def align_windows(windows, del_, ext, matrix, device=None, want_traceback=True, 
     (engine/calc.rs:107-136 spawns threads stepping over windows and aligns them one by one).
 
     windows: iterable of residue-code arrays.  Returns (results ndarray, [PWMAlignment | None per window])."""
-    lib = _ffi.load()
     wins = [np.asarray(w, dtype=np.uint8) for w in windows]
     n = len(wins)
-    m = np.asarray(matrix, dtype=np.float64)
-    W = m.shape[1]
     t_len = np.array([len(w) for w in wins], dtype=np.uint64)
     t_off = np.zeros(n, dtype=np.uint64)
     if n > 1:
         t_off[1:] = np.cumsum(t_len)[:-1]
     seqs = np.concatenate(wins) if n else np.zeros(0, dtype=np.uint8)
+    return align_window_offsets(seqs, t_off, t_len, del_, ext, matrix, device=device, want_traceback=want_traceback,
+                                alphabet=alphabet)
+
+
+def align_window_offsets(sequence, starts, lengths, del_, ext, matrix, device=None, want_traceback=True, alphabet=DNA,
+                         want_alignments=True, reuse=None):
+    """The same for windows given as (start, length) into ONE residue-code array -- how the engine walks a chromosome
+    (engine/calc.rs:111-124: `sequence[j..j + window]`): overlapping windows are not copied, the array goes to the GPU once per
+    chunk.  `reuse`: a dict that keeps the output buffers between calls (a fresh 300 MB buffer costs more in page faults than
+    the call itself).  Returns (results ndarray, [PWMAlignment | None per window] or None)."""
+    lib = _ffi.load()
+    seqs = np.ascontiguousarray(sequence, dtype=np.uint8)
+    t_off = np.ascontiguousarray(starts, dtype=np.uint64)
+    t_len = np.ascontiguousarray(lengths, dtype=np.uint64)
+    n = len(t_off)
+    m = np.asarray(matrix, dtype=np.float64)
+    W = m.shape[1]
     q_off = np.zeros(n, dtype=np.uint64)
     q_len = np.full(n, W, dtype=np.uint64)
     outs = _ffi.OUT_SCORE | (_ffi.OUT_TRACEBACK if want_traceback else 0)
@@ -99,11 +113,18 @@ def align_windows(windows, del_, ext, matrix, device=None, want_traceback=True, 
     tb_off = np.zeros(n, dtype=np.uint64)
     if n > 1:
         tb_off[1:] = np.cumsum(tb_sz)[:-1]
-    tb = np.zeros(int(tb_sz.sum()) + 8, dtype=np.uint8)
+    need = (int(tb_sz.sum()) if want_traceback else 0) + 8
+    tb = reuse.get("tb") if reuse is not None else None
+    if tb is None or len(tb) < need:
+        tb = np.zeros(need, dtype=np.uint8)
+        if reuse is not None:
+            reuse["tb"] = tb
     st = lib.aln_align_batch(runtime.context(device), C.byref(p), seqs.ctypes.data, q_off.ctypes.data,
                              q_len.ctypes.data, t_off.ctypes.data, t_len.ctypes.data, n, res.ctypes.data,
                              tb.ctypes.data if want_traceback else None, tb_off.ctypes.data if want_traceback else None)
     runtime.raise_for_status(st, "aln_align_batch(PWM)")
+    if not want_alignments or not want_traceback:
+        return res, None if not want_alignments else [None] * n
     alns = []
     for i in range(n):
         if not want_traceback or res["status"][i] != 0:

@@ -873,6 +873,25 @@ def test_concurrent_callers_share_the_slot_pool(orc, blosum62):
     assert serial_p[0][0].score == want["score"] and serial_p[0][1].tolist() == want["qa"].tolist()
 
 
+def test_pwm_windows_by_offsets_equal_copied_windows(orc):
+    """engine/calc.rs:111-124 walks a chromosome in overlapping windows: align_window_offsets takes (start, length) into the one
+    array -- same results as the windows copied out one by one, and as the oracle."""
+    from aligner_amd.pwm import align_window_offsets, align_windows
+    rng = np.random.default_rng(77)
+    pwm = rng.integers(-2, 3, (4, 40)).astype(np.float64)
+    chrom = rng.integers(0, 4, 9000).astype(np.uint8)
+    starts = np.arange(0, 8000, 13, dtype=np.uint64)
+    lens = rng.integers(1, 120, len(starts)).astype(np.uint64)
+    res, alns = align_window_offsets(chrom, starts, lens, 3, 1, pwm)
+    res2, alns2 = align_windows([chrom[int(a):int(a + b)] for a, b in zip(starts, lens)], 3, 1, pwm)
+    assert (res == res2).all()
+    for i in range(0, len(starts), 5):
+        ref = orc.align_pwm(chrom[int(starts[i]):int(starts[i] + lens[i])], 3, 1, pwm)
+        assert res["f"][i] == ref["f"] and alns[i].coords == ref["coords"] == alns2[i].coords
+        assert alns[i].numbered.tolist() == ref["numbered"].tolist() == alns2[i].numbered.tolist()
+        assert alns[i].query.tolist() == ref["qal"].tolist()
+
+
 def test_c3_full_batch_matches_oracle(orc):
     """BASELINE C3 at full size (10 000 read pairs of 150 bp, core global, +5/-4, 10/1): every summary and both strings
     against the oracle run on the same batch (2.3e8 cells: seconds on the host)."""
