@@ -358,6 +358,18 @@ def main():
         if not args.no_end_to_end:
             line["end_to_end"], e2e_res = end_to_end(batch, S, local_rank)
             assert (e2e_res == res).all(), "the pipelined call and the staged batch disagree"
+            # the same call from a process of its own (tools/bench_e2e.py as a child: no torch, no other stream sharing the GPU's
+            # hardware queues) -- what a standalone caller of the C ABI sees
+            try:
+                import subprocess
+                env = dict(os.environ, E2E_JSON="1")
+                outp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_e2e.py"), str(args.pairs), "3"], env=env,
+                                      capture_output=True, text=True, timeout=180).stdout
+                for ln in outp.splitlines():
+                    if ln.startswith("E2E_JSON "):
+                        line["end_to_end"]["standalone_process"] = json.loads(ln[len("E2E_JSON "):])
+            except Exception as e:                       # noqa: BLE001 -- the in-process figure stands on its own
+                line["end_to_end"]["standalone_process"] = {"error": str(e)[:200]}
         if not args.no_small_configs:
             line["configs"] = small_configs(S, local_rank, stream, torch)
         if not args.no_single_pair:

@@ -25,6 +25,7 @@ tb_off, total = b.tb_layout()
 tb = np.zeros(max(total, 1), dtype=np.uint8)
 ctx = runtime.context(0)
 print("pairs %d cells %.4g seq bytes %.1f MB tb bytes %.1f MB" % (pairs, b.cells, len(b.seqs) / 1e6, total / 1e6), flush=True)
+times = []
 for i in range(calls + 1):
     t0 = time.perf_counter()
     st = lib.aln_align_batch(ctx, C.byref(p), b.seqs.ctypes.data, b.q_off.ctypes.data, b.q_len.ctypes.data, b.t_off.ctypes.data,
@@ -32,5 +33,12 @@ for i in range(calls + 1):
                              tb_off.ctypes.data if want_tb else None)
     dt = time.perf_counter() - t0
     assert st == 0, (st, _ffi.last_error())
+    times.append(dt)
     print("call %d%s: %.2f ms  %.1f GCUPS   ok %d" % (i, " (cold pool)" if i == 0 else "", dt * 1e3, b.cells / dt / 1e9,
                                                  int((res["status"] == 0).sum())), flush=True)
+if os.environ.get("E2E_JSON"):
+    import json
+    warm = sorted(times[1:])
+    med = warm[len(warm) // 2]
+    print("E2E_JSON " + json.dumps({"ms": round(med * 1e3, 3), "gcups": round(b.cells / med / 1e9, 2), "calls": calls,
+                                     "pairs_ok": int((res["status"] == 0).sum())}), flush=True)
