@@ -476,6 +476,49 @@ def test_pwm_errors_and_empty_result(orc):
     assert ref["f"] == 0.0 and ref["coords"] == ((1, 1), (1, 1))
 
 
+def test_pwm_empty_sequence_is_ok_and_empty(orc):
+    """PWMAligner with an empty sequence: the reference's loops do not run, argmax is (0, 0), the traceback stops at once --
+    Ok with an empty alignment and f = 0 (pwm/mod.rs:52-108), not a panic; alone and inside a window batch."""
+    from aligner_amd.pwm import PWMAligner, align_windows
+    pwm = np.arange(20, dtype=np.float64).reshape(4, 5) - 6
+    r = PWMAligner.from_seqs(np.zeros(0, np.uint8)).perform_alignment(3, 1, pwm)
+    ref = orc.align_pwm(np.zeros(0, np.uint8), 3, 1, pwm)
+    assert ref["status"] == 0 and ref["f"] == 0.0 and len(ref["numbered"]) == 0
+    assert r.alignment.f == 0.0 and len(r.alignment.numbered) == 0 and r.alignment.coords == ref["coords"]
+    res, alns = align_windows([np.array([0, 1, 2], np.uint8), np.zeros(0, np.uint8), np.array([3, 3, 1, 0], np.uint8)], 3, 1, pwm)
+    assert res["status"].tolist() == [0, 0, 0] and res["aln_len"][1] == 0 and res["f"][1] == 0.0
+    for i, w in enumerate(([0, 1, 2], [], [3, 3, 1, 0])):
+        ref = orc.align_pwm(np.array(w, np.uint8), 3, 1, pwm)
+        assert res["f"][i] == ref["f"] and alns[i].numbered.tolist() == ref["numbered"].tolist()
+
+
+def test_larger_alphabets_and_strided_matrices(orc):
+    """Alphabets of 28 letters (S and four waves' query profiles still fit 64 KiB of LDS: fast kernels) and of 40 and 64 letters
+    (they do not: generic kernels) against the oracle; and a matrix handed over as a broadcast / transposed numpy view
+    (row stride 0 or not a multiple of the row length) is compacted on the way in."""
+    rng = np.random.default_rng(64)
+    for A in (28, 40, 64):
+        S = rng.integers(-6, 9, (A, A)).astype(np.float64)
+        q = rng.integers(0, A, 300).astype(np.uint8)
+        t = rng.integers(0, A, 700).astype(np.uint8)
+        for sem in (_ffi.CORE_LOCAL, _ffi.CORE_GLOBAL, _ffi.LEGACY_LOCAL):
+            res = check_pair(orc, sem, q, t, 7, 7 if sem == _ffi.LEGACY_LOCAL else 2, S, full=True, directions_only=True)
+            assert res.flags & 1
+        b = PairBatch.from_pairs([(rng.integers(0, A, int(rng.integers(5, 400))).astype(np.uint8),
+                                   rng.integers(0, A, int(rng.integers(5, 900))).astype(np.uint8)) for _ in range(40)])
+        _check_batch(orc, b, _ffi.CORE_LOCAL, 7, 2, S)
+    base = rng.integers(-4, 6, 24).astype(np.float64)
+    views = [np.broadcast_to(base, (24, 24)), np.asfortranarray(rng.integers(-4, 6, (24, 24)).astype(np.float64)),
+             rng.integers(-4, 6, (24, 48)).astype(np.float64)[:, ::2]]
+    q = rng.integers(0, 20, 90).astype(np.uint8)
+    t = rng.integers(0, 20, 130).astype(np.uint8)
+    for S in views:
+        check_pair(orc, _ffi.CORE_LOCAL, q, t, 11, 2, np.array(S), full=False)
+        res, qa, ta, _, _ = runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, S)
+        ref = orc.align(orc.CORE_LOCAL, q, t, 11, 2, np.ascontiguousarray(S))
+        assert res.score == ref["score"] and qa.tolist() == ref["qa"].tolist()
+
+
 def test_pwm_window_batch(orc):
     """latent-repeat-search's inner loop as one batch: 400 windows of 330 nt against one 300-column PWM."""
     from aligner_amd.pwm import align_windows
