@@ -44,7 +44,8 @@ def build(force=False, remarks=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if remarks else []) + \
+    # ALN_CXXFLAGS: extra flags for an instrumented build (-DALN_STAMPS: per-pair time stamps for tools/tail_timeline.py)
+    cmd = [hipcc] + FLAGS + os.environ.get("ALN_CXXFLAGS", "").split() + (["-Rpass-analysis=kernel-resource-usage"] if remarks else []) + \
         [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     subprocess.check_call(cmd)
     return LIB

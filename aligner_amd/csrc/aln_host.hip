@@ -512,6 +512,7 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
             k.counter_bytes = 256 + 4ull * k.n_small;
         }
     }
+    if (const char *e = getenv("ALN_FILL_WGS")) k.grid = std::max(1u, std::min(k.grid, (uint32_t)atoi(e)));   // experiments: fewer resident fill waves
     const uint64_t sc_size = c.is_int ? 4 : 8;
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;

@@ -715,7 +715,13 @@ void aln_fill_fast_kernel(FillArgs a)
         else if (!pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, in.lane)) skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, in.lane);
         else {
             set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
+#ifdef ALN_STAMPS                                        // tools/tail_timeline.py: when did which wave work on this pair (score-only runs)
+            const uint64_t ts = wall_clock64();
+#endif
             plain = do_pair_fast<SEM, PWM>(in, fs, a, desc, res, (int)a.del, (int)a.ext);
+#ifdef ALN_STAMPS
+            if (in.lane == 0) { res.aln_len = (uint32_t)ts; res.start_x = (uint32_t)wall_clock64(); res.start_y = wave; }
+#endif
         }
         pair_done(a, in.lane, pair, plain);
     }
