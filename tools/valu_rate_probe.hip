@@ -157,6 +157,29 @@
     "v_lshl_add_u32 %" S(i) ", %" S(i) ", 11, %10\n\t"                                                         \
     "v_max_i32 %" S(i) ", %" S(i) ", %9\n\t"
 
+// The same cell for TWO cells in packed 16-bit halves (prototype of a v_pk_*_i16 fill: T = 4H + 2 in 16 bits, two independent
+// cells per register): profile bytes into both halves (2 SDWA adds), top/left keys (2 pk_add), 2 pk_max, the two carried forms
+// (nt and nt - 1: 2 and_or), Beginning tag (pk_max_u16), next row's penalty (pk_min_u16 + pk_mad_i16), direction bits (and +
+// lshl_or), one end-cell key per half (lshl_or, and_or) + their max = 16 VALU + 2 max for 2 cells
+#define OP_PKCELL(i)                                                                                           \
+    "v_add_u16_sdwa %" S(i) ", %" S(i) ", sext(%8) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:BYTE_1\n\t" \
+    "v_add_u16_sdwa %" S(i) ", %" S(i) ", sext(%9) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2\n\t" \
+    "v_pk_add_i16 %" S(i) ", %" S(i) ", %8\n\t"                                                                \
+    "v_pk_add_i16 %" S(i) ", %" S(i) ", %9\n\t"                                                                \
+    "v_pk_max_i16 %" S(i) ", %" S(i) ", %8\n\t"                                                                \
+    "v_pk_max_i16 %" S(i) ", %" S(i) ", %9\n\t"                                                                \
+    "v_and_or_b32 %" S(i) ", %" S(i) ", %8, %9\n\t"                                                            \
+    "v_and_or_b32 %" S(i) ", %" S(i) ", %9, %8\n\t"                                                            \
+    "v_pk_max_u16 %" S(i) ", %" S(i) ", %8\n\t"                                                                \
+    "v_pk_min_u16 %" S(i) ", %" S(i) ", %9\n\t"                                                                \
+    "v_pk_mad_i16 %" S(i) ", %" S(i) ", %8, %9\n\t"                                                            \
+    "v_and_b32 %" S(i) ", %" S(i) ", %8\n\t"                                                                   \
+    "v_lshl_or_b32 %" S(i) ", %" S(i) ", 2, %9\n\t"                                                            \
+    "v_lshl_or_b32 %" S(i) ", %" S(i) ", 16, %10\n\t"                                                          \
+    "v_and_or_b32 %" S(i) ", %" S(i) ", %8, %10\n\t"                                                           \
+    "v_max_i32 %" S(i) ", %" S(i) ", %9\n\t"                                                                   \
+    "v_max_i32 %" S(i) ", %" S(i) ", %8\n\t"
+
 #define PROBE(NAME, OP, PER) PROBE_T(NAME, OP, PER, uint32_t)
 PROBE(add_u32, OP_ADD, 1)
 PROBE(sub_u32, OP_SUB, 1)
@@ -190,6 +213,7 @@ PROBE(bfe_u32, OP_BFE, 1)
 PROBE(mad_u32_u24, OP_MAD, 1)
 PROBE(min_max_i32, OP_MINMAX, 2)
 PROBE(fill_cell_11, OP_CELL, 11)
+PROBE(pk16_two_cells_17, OP_PKCELL, 17)
 PROBE(mix_max3_plus_sadd, OP_MAX3_SADD, 1)
 PROBE(mix_max3_plus_snop, OP_MAX3_SNOP, 1)
 PROBE(mix_max3_plus_scmp_branch, OP_MAX3_SCMP_BR, 1)
@@ -262,7 +286,7 @@ static const Entry entries[] = {
     E(lshl_add_u32_sgpr), E(add_u32_sdwa), E(mov_dpp_wave_shr), E(mov_dpp_row_ror), E(cmp_vcc_plus_cndmask),
     E(cndmask_b32), E(cmp_eq_vcc), E(cmp_eq_sgpr), E(pk_add_i16), E(pk_max_i16), E(pk_add_u16), E(pk_sub_u16_clamp),
     E(fma_f32), E(add_f32), E(readlane), E(writelane), E(perm_b32), E(xor_b32), E(mov_b32), E(lshrrev_b32), E(bfe_u32),
-    E(mad_u32_u24), E(min_max_i32), E(fill_cell_11),
+    E(mad_u32_u24), E(min_max_i32), E(fill_cell_11), E(pk16_two_cells_17),
     E(exec0_4max3_per_1), E(exec1lane_4max3_per_1), E(exec_toggle_plus_max3),
     E(mix_max3_plus_sadd), E(mix_max3_plus_snop), E(mix_max3_plus_scmp_branch), E(mix_max3_plus_2salu), E(mix_add_plus_sadd), E(mix_max3_plus_vadd), E(dep_chain_max3), E(dep_chain_add), E(dep_2chains_max3),
     E(max_f32), E(min_f32), E(max3_f32), E(med3_f32), E(max_f32_negmod), E(and_b32), E(or_b32), E(and_b32_imm), E(lshlrev_b32), E(ashrrev_i32), E(cndmask_vcc_src), E(cndmask_sgpr_src), E(cmp_gt_f32), E(cmp_gt_i32), E(sub_f32_abs_clamp), E(mul_f32), E(cvt_f32_ubyte1), E(cvt_f32_i32), E(cvt_i32_f32), E(fma_mix_f32), E(pk_add_f32), E(pk_fma_f32), E(pk_mov_b32), E(max_f64), E(add_f64), E(pk_max_f16), E(max_f16), E(max_i16), E(add_u16), E(add_co_u32), E(bfi_b32), E(or3_b32), E(lshl_or_b32), E(xad_u32), E(min3_i32), E(mul_lo_u32), E(mul_u32_u24), E(floor_f32), E(add_f32_dpp), E(add_u32_dpp_row_shr), E(mov_b32_sdwa), E(accvgpr_write), E(accvgpr_read), E(fma_f32_sgpr), E(fmac_f32), E(add_u32_inline_imm), E(add_u32_literal), E(add_u32_sgpr),
