@@ -1245,12 +1245,16 @@ __device__ __forceinline__ StripWindow stage_window(const uint32_t *wbase, uint3
 // upwards (then cy == y0).  `ops` (optional) receives the tags.  fetch(kb, lane) returns the direction word of block kb
 // of that lane.  The interior loop is branch-lean (one exit test, one load, shifts); the borders of the global
 // semantics (D[0][x] = Left, D[y][0] = Top: simple/mod.rs:55-67) are whole runs and are handled after it.
+// `cap` (exit maps only): a walk that has not left the strip after that many steps is given up (*gave_up): far from the real
+// path the tags are long gap runs, and one thread following a 900-column Left run held up its whole block.
 template <class Fetch>
 __device__ __forceinline__ bool walk_in_strip(Fetch fetch, uint32_t y0, uint32_t lgR, uint32_t N, bool global,
-                                              uint32_t &cy, uint32_t &cx, uint32_t &steps, uint8_t *ops)
+                                              uint32_t &cy, uint32_t &cx, uint32_t &steps, uint8_t *ops,
+                                              uint32_t cap = 0xffffffffu, bool *gave_up = nullptr)
 {
     const uint32_t R = 1u << lgR, sh = 4u - lgR;
     uint32_t y = cy, x = cx, n = steps;
+    const uint32_t n_stop = cap == 0xffffffffu ? cap : steps + cap;
     bool beginning = false;
     bool go = (y > y0 && x != 0);
     while (go) {                                       // single exit, body predicated: the loop is one exec-mask update
@@ -1265,8 +1269,9 @@ __device__ __forceinline__ bool walk_in_strip(Fetch fetch, uint32_t y0, uint32_t
         n += beginning ? 0u : 1u;
         y -= (tag == 0u || tag == 2u) ? 1u : 0u;       // 0 Diagonal, 1 Left, 2 Top (3 moves nothing)
         x -= (tag <= 1u) ? 1u : 0u;
-        go = !beginning && y > y0 && x != 0;
+        go = !beginning && y > y0 && x != 0 && n < n_stop;
     }
+    if (gave_up) *gave_up = !beginning && y > y0 && x != 0;
     bool ended = beginning;
     if (!beginning) {
         if (!global) ended = (y == 0 || x == 0);                         // local: every border cell is Beginning
@@ -1331,8 +1336,11 @@ extern "C" __global__ __launch_bounds__(256) void aln_tb_single_maps_kernel(Trac
         if (__builtin_expect(rel >= q_n, 0)) word = wbase[(((uint64_t)q * 64u + lane) << 2) + (kb & 3u)];   // left the window (rare)
         return word;
     };
-    const bool stopped = walk_in_strip(fetch, y0, lgR, d.N, global, cy, cx, steps, nullptr);
-    a.map[(size_t)s * (d.N + 1) + x] = make_uint4(cx, cy, steps, stopped ? 1u : 0u);
+    // a path crosses the strip in rows .. rows + (gap columns) steps; beyond twice the rows + 64 the entry is marked unusable
+    // (2) and the chain kernel, should the real path ever come this way, walks the strip itself
+    bool gave_up = false;
+    const bool stopped = walk_in_strip(fetch, y0, lgR, d.N, global, cy, cx, steps, nullptr, 2u * rows + 64u, &gave_up);
+    a.map[(size_t)s * (d.N + 1) + x] = make_uint4(cx, cy, steps, gave_up ? 2u : stopped ? 1u : 0u);
 }
 
 // one thread: from the end cell through its own strip, then strip by strip through the maps
@@ -1369,10 +1377,11 @@ extern "C" __global__ void aln_tb_single_chain_kernel(TraceSingleArgs a)
             --s;
             a.seg[s] = make_uint4(cy, cx, off, 1);
             uint32_t c_lo, c_hi;
-            if (tb_band(ey, ex, cy, d.N, c_lo, c_hi) && cx >= c_lo && cx <= c_hi) {
-                const uint4 m = a.map[(size_t)s * (d.N + 1) + cx];
+            uint4 m = make_uint4(0, 0, 0, 2);
+            if (tb_band(ey, ex, cy, d.N, c_lo, c_hi) && cx >= c_lo && cx <= c_hi) m = a.map[(size_t)s * (d.N + 1) + cx];
+            if (m.w != 2u) {
                 cx = m.x; cy = m.y; off += m.z; stopped = m.w != 0;
-            } else {                                             // outside the band: walk this strip here
+            } else {                                             // outside the band, or an entry the map gave up on: walk this strip here
                 const uint32_t *wb = reinterpret_cast<const uint32_t *>(a.dirs + d.dir_off + s * aln_uniform_strip_bytes(d.N, a.R));
                 auto fetch2 = [&](uint32_t kb, uint32_t lane) -> uint32_t { return wb[(((uint64_t)(kb >> 2) * 64u + lane) << 2) + (kb & 3u)]; };
                 uint32_t st = 0;
