@@ -139,6 +139,29 @@ struct TraceArgs {
     uint64_t wait_ticks;      // give up on a chunk after this many 100 MHz ticks (the sweep walks what is left)
 };
 
+// One pair of the generic kernels (f64, or int32 without the fast path's conditions), filled by ONE workgroup: wave s owns strip s
+// (64 R rows), the strips are pipelined through LDS rings.  Directions in the uniform-R layout of the single-pair route.
+struct WgArgs {
+    const uint8_t *seqs;
+    PairDesc *descs;
+    uint32_t pair;
+    uint8_t *dirs;
+    aln_pair_result *results;
+    const void *matrix;       // device copy, contiguous rows x cols, int32 or double
+    uint32_t rows, cols;
+    double del, ext;
+    int32_t semantics;
+    uint32_t R, ns;           // rows per lane (1 or 2), strips = waves of the workgroup (<= 16)
+    uint32_t max_passes;
+    uint32_t store_dirs;
+    uint8_t *scratch;         // (max(N, M) + 66) scores: the column of the strict-order routine, should the passes not converge
+};
+#define ALN_WG_RING 256u      // entries of a hand-off ring (a strip's bottom row, by column & 255)
+__host__ __device__ inline uint32_t aln_wg_lds_bytes(uint32_t rows, uint32_t cols, uint32_t sc_size, uint32_t ns, uint32_t N)
+{
+    return ((rows * cols * sc_size + 15u) & ~15u) + ns * ALN_WG_RING * sc_size + 2u * ((N + 66u + 15u) & ~15u) + 64u * 4u + ns * 32u;
+}
+
 // Parallel traceback of one large pair (uniform-R layout): per strip and entry column an "exit map", then a short
 // serial chain through the maps, then one walker per strip that writes its segment of the tag string.
 struct TraceSingleArgs {

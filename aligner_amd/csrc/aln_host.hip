@@ -52,6 +52,7 @@ extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s);
 extern "C" void aln_launch_traceback_expand_single(const TraceArgs *a, uint32_t pair, hipStream_t s);
 extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_serial, hipStream_t s);
+extern "C" void aln_launch_wgpipe(const WgArgs *a, int is_int, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hipStream_t s);
 extern "C" void aln_launch_single_repair(const SingleArgs *a, uint32_t N, hipStream_t s);
 extern "C" uint32_t aln_single_lds_bytes(uint32_t rows, uint32_t cols, uint32_t R, uint32_t N, uint32_t W);
@@ -365,6 +366,7 @@ struct Chunk {
     std::vector<PairDesc> descs;
     std::vector<uint32_t> order;      // LPT order of the device work queue (pairs of the batch kernel)
     std::vector<uint32_t> single_pairs, single_r;   // pairs routed to the single-pair (one wave per strip) kernel
+    std::vector<uint32_t> wg_pairs, wg_r;           // generic kernels: pairs filled by one workgroup each (aln_fill_wgpipe_kernel)
     size_t n_small = 0;
     uint64_t cells = 0, max_cells = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, hmat_elems = 0;
     uint32_t max_len = 1, grid = 1, zrow_bytes = 0, lds_bytes = 0, prof_stride = 0, tb_waves = 0, single_max_n = 0, cascade_rows = 1;
@@ -452,6 +454,19 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
                 k.tbmap_entries = std::max<uint64_t>(k.tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
             }
         }
+        // Generic kernels (real-valued matrix, or an integer one outside the fast path's limits): a chunk of a few pairs gives each
+        // pair a whole workgroup, one wave per 64 R-row strip (<= 16 strips), instead of one wave -- the call HeuristicAligner makes
+        // once per iteration (heuristic/mod.rs:58-77).  Not with the H dump (the generic strip kernel writes it), not for PWM scoring.
+        if (!single && !c.fast && !pwm && !c.want_h && !c.p.force_serial && !getenv("ALN_NO_WGPIPE") && n <= 16 && pc >= (1ull << 14) &&
+            d.N >= 16 && d.N <= 8192 && d.M >= 65 && d.M <= 2048) {
+            const uint32_t R = d.M > 1024 ? 2u : 1u, ns = (d.M + 64 * R - 1) / (64 * R);
+            if (aln_wg_lds_bytes(c.rows, c.cols, c.is_int ? 4u : 8u, ns, d.N) <= 64u * 1024u) {
+                dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * aln_uniform_strip_bytes(d.N, R));
+                k.wg_pairs.push_back((uint32_t)i);
+                k.wg_r.push_back(R);
+                k.tbmap_entries = std::max<uint64_t>(k.tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
+            }
+        }
         d.dir_off = dir_total;
         if (c.store_dirs) dir_total += dbytes;
         if (c.want_h) { d.h_off = hm_total; hm_total += (uint64_t)(d.N + 1) * (d.M + 1); }
@@ -465,6 +480,7 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
     {
         std::vector<char> is_single(n, 0);
         for (uint32_t i : k.single_pairs) is_single[i] = 1;
+        for (uint32_t i : k.wg_pairs) is_single[i] = 1;
         for (size_t i = 0; i < n; ++i) if (!is_single[i]) k.order.push_back((uint32_t)i);
     }
     k.n_small = k.order.size();
@@ -569,7 +585,8 @@ static int slot_ensure(Slot &s, const Call &c, const Chunk &k, const Need *need 
     ENS(results, k.n * sizeof(aln_pair_result));
     ENS(tb, k.tb_bytes);
     ENS(tags, k.tag_bytes);
-    ENS(scratch, (uint64_t)k.grid * 4 * k.scratch_stride);
+    ENS(scratch, std::max<uint64_t>((uint64_t)k.grid * 4 * k.scratch_stride, k.wg_pairs.empty() ? 0 : ((uint64_t)k.max_len + 66) * 8));
+    if (!k.wg_pairs.empty()) ENS(tbmap, k.tbmap_entries * 16);
     ENS(matrix, (uint64_t)c.rows * c.cols * (c.is_int ? 4 : 8));
     if (c.pwm && c.fast) ENS(pwm_words, (uint64_t)c.cols * 4);
     if (c.want_h) ENS(hmat, k.hmat_elems * (c.is_int ? 4 : 8));
@@ -737,13 +754,24 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
         }
         HIPCHK(hipGetLastError());
     }
+    for (size_t j = 0; j < k.wg_pairs.size(); ++j) {
+        const PairDesc &d = k.descs[k.wg_pairs[j]];
+        WgArgs wa{};
+        wa.seqs = s.seqs.as<uint8_t>(); wa.descs = s.descs.as<PairDesc>(); wa.pair = k.wg_pairs[j]; wa.dirs = s.dirs.as<uint8_t>();
+        wa.results = s.results.as<aln_pair_result>(); wa.matrix = s.matrix.p; wa.rows = c.rows; wa.cols = c.cols;
+        wa.del = c.p.del; wa.ext = c.p.ext; wa.semantics = c.semantics; wa.R = k.wg_r[j]; wa.ns = (d.M + 64 * wa.R - 1) / (64 * wa.R);
+        wa.max_passes = c.p.max_passes; wa.store_dirs = c.store_dirs ? 1u : 0u; wa.scratch = s.scratch.as<uint8_t>();
+        aln_launch_wgpipe(&wa, c.is_int ? 1 : 0, aln_wg_lds_bytes(c.rows, c.cols, c.is_int ? 4u : 8u, wa.ns, d.N), st);
+        launches++;
+        HIPCHK(hipGetLastError());
+    }
     if (ev) HIPCHK(hipEventRecord(ev[1], st));
     if (s.ev_fill) HIPCHK(hipEventRecord(s.ev_fill, st));
     if (c.want_tb && c.store_dirs) {
         if (overlap) HIPCHK(hipStreamWaitEvent(st, s.ev_join, 0));
         // every pair except those in the uniform-R layout (handled below); pairs the single-pair route hands to the strict-order
         // kernel (row-major layout) are walked by these two as well
-        const bool batch_tb = k.n_small != 0 || c.semantics == ALN_CORE_LOCAL;
+        const bool batch_tb = k.n_small != 0 || c.semantics == ALN_CORE_LOCAL || !k.wg_pairs.empty();
         if (batch_tb) aln_launch_traceback(&ta, st);
         for (size_t j = 0; j < k.single_pairs.size(); ++j) {
             const PairDesc &d = k.descs[k.single_pairs[j]];
@@ -752,6 +780,17 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
             tsa.results = s.results.as<aln_pair_result>(); tsa.tb = s.tb.as<uint8_t>(); tsa.tags = s.tags.as<uint8_t>();
             tsa.semantics = c.semantics;
             tsa.R = k.single_r[j]; tsa.ns = (d.M + 64 * tsa.R - 1) / (64 * tsa.R);
+            tsa.map = s.tbmap.as<uint4>(); tsa.seg = s.tbmap.as<uint4>() + (uint64_t)tsa.ns * (d.N + 1);
+            aln_launch_traceback_single(&tsa, d.N, st);
+            aln_launch_traceback_expand_single(&ta, tsa.pair, st);
+        }
+        for (size_t j = 0; j < k.wg_pairs.size(); ++j) {      // the same parallel traceback for the pairs one workgroup filled
+            const PairDesc &d = k.descs[k.wg_pairs[j]];
+            TraceSingleArgs tsa{};
+            tsa.seqs = s.seqs.as<uint8_t>(); tsa.descs = s.descs.as<PairDesc>(); tsa.pair = k.wg_pairs[j]; tsa.dirs = s.dirs.as<uint8_t>();
+            tsa.results = s.results.as<aln_pair_result>(); tsa.tb = s.tb.as<uint8_t>(); tsa.tags = s.tags.as<uint8_t>();
+            tsa.semantics = c.semantics;
+            tsa.R = k.wg_r[j]; tsa.ns = (d.M + 64 * tsa.R - 1) / (64 * tsa.R);
             tsa.map = s.tbmap.as<uint4>(); tsa.seg = s.tbmap.as<uint4>() + (uint64_t)tsa.ns * (d.N + 1);
             aln_launch_traceback_single(&tsa, d.N, st);
             aln_launch_traceback_expand_single(&ta, tsa.pair, st);

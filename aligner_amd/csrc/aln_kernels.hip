@@ -451,6 +451,154 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
     }
 }
 
+// ---------------------------------------------------------------- one pair, generic kernels, one WORKGROUP per pair
+// The generic kernels above give a pair one wave: 4.4 ms for a 1000 x 1000 pair with a real-valued matrix (every iteration of
+// HeuristicAligner, heuristic/mod.rs:58-77, is such a call).  Here wave s of one workgroup owns strip s (64 R rows) and the
+// strips run as a pipeline: the bottom row of strip s travels to strip s+1 through an LDS ring, 16 columns at a time
+// (prod[s] = columns published, cons[s] = the step whose 16 columns strip s has taken; both in LDS, workgroup-scope
+// acquire / release).  Everything else -- cell, penalty rule, advice passes, end cell -- is run_strip's; the directions go
+// to the uniform-R layout, so the parallel traceback of the single-pair route applies.  Every wait is bounded and raises the
+// workgroup's abort flag; an aborted or non-converging fill ends in the strict-order routine like the other kernels.
+template <typename SC> struct WgShared {
+    const SC *S;
+    SC *rings;
+    uint8_t *advice, *zrow;
+    uint32_t *prod, *cons, *flags;      // flags[0] abort, flags[1] advice mismatch
+};
+
+template <typename SC, int SEM, int R>
+__device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, const WgShared<SC> &sh, const uint32_t strip, const bool last,
+                                         const bool hazard, const int lane, SC &bv, uint32_t &by, uint32_t &bx, SC &corner)
+{
+    using O = ScOps<SC>;
+    constexpr int SPB = (int)aln_spb(R);
+    const uint32_t N = d.N, M = d.M;
+    const uint8_t *q = a.seqs + d.q_off, *t = a.seqs + d.t_off;
+    const uint32_t y0 = strip * 64u * R;
+    const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
+    const uint32_t L = (rows + R - 1) / R;
+    const uint32_t nsteps = last ? N + L - 1 : N + 63;
+    const uint32_t yb = y0 + (uint32_t)lane * R;
+    const uint32_t lb = (rows - 1) / R, rb = (rows - 1) % R;
+    const SC del = O::from_double(a.del), ext = O::from_double(a.ext);
+    SC *ring_in = sh.rings + (size_t)(strip ? strip - 1 : 0) * ALN_WG_RING, *ring_out = sh.rings + (size_t)strip * ALN_WG_RING;
+
+    int tc[R];
+    SC Hl[R], rbv[R];
+    uint32_t rbx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t y = yb + 1 + r;
+        tc[r] = (y <= M) ? (int)t[y - 1] * (int)a.cols : 0;
+        Hl[r] = border_left<SC, SEM>(y, M, del);
+        rbv[r] = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : O::lowest();
+        rbx[r] = 0;
+    }
+    SC hdiag = border_left<SC, SEM>(yb, M, del);
+    SC bottom = Hl[R - 1];
+    SC inchunk = (SC)0;
+    uint32_t advchunk = 0;
+    bool dead = false;                                 // this wave gave up waiting (the abort flag is up)
+
+    uint32_t *dirw = reinterpret_cast<uint32_t *>(a.dirs + d.dir_off + (uint64_t)strip * aln_uniform_strip_bytes(N, R));
+    const uint32_t nkb = (nsteps + SPB - 1) / SPB;
+    for (uint32_t kb = 0; kb < nkb && !dead; ++kb) {
+        uint32_t dw = 0;
+#pragma unroll
+        for (int kk = 0; kk < SPB; ++kk) {
+            const uint32_t k = kb * SPB + kk;
+            if ((k & 15u) == 0) {                      // wave-uniform: the next 16 columns of the row above, lane j <- column k + 1 + j
+                const uint32_t xi = k + 1 + (uint32_t)lane;
+                if (strip > 0) {
+                    const uint32_t need = min(N, k + 16u);
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(sh.prod + strip - 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22) || __hip_atomic_load(sh.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { dead = true; break; }
+                    }
+                    inchunk = (lane < 16 && xi <= N && !dead) ? ring_in[xi & (ALN_WG_RING - 1u)] : (SC)0;
+                    if (lane == 0) __hip_atomic_store(sh.cons + strip, k + 16u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // columns <= k + 16 are in registers
+                }
+                if (SEM == ALN_CORE_LOCAL && strip == 0 && hazard) advchunk = (lane < 16 && xi <= N) ? sh.advice[xi] : 0u;
+                if (!last && k + 16u > 62u + ALN_WG_RING) {
+                    // the next 16 steps write columns up to k - 46 into slots the strip below must have emptied
+                    const uint32_t x_max = k + 16u - 62u;
+                    uint32_t spins = 0;
+                    while (!dead && __hip_atomic_load(sh.cons + strip + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + ALN_WG_RING < x_max) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22) || __hip_atomic_load(sh.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) dead = true;
+                    }
+                }
+            }
+            SC top0;
+            if (strip == 0) top0 = border_top<SC, SEM>(k + 1, N, del);
+            else top0 = O::rdlane(inchunk, (int)(k & 15u));
+            const SC topIn = O::shr1(top0, bottom);
+            const uint32_t adv = (SEM == ALN_CORE_LOCAL && strip == 0)
+                                     ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, (int)(k & 15u)) : 0u;
+            const uint32_t xm1 = k - (uint32_t)lane;
+            if (xm1 < N) {
+                const uint32_t x = xm1 + 1;
+                const int qc = (int)q[xm1];
+                SC top = topIn, diag = hdiag;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t y = yb + 1 + r;
+                    const SC sc = sh.S[tc[r] + qc];
+                    SC p;
+                    if (SEM == ALN_CORE_GLOBAL) p = (r == 0 && y == 1 && x == 1) ? del : ext;
+                    else if (SEM == ALN_CORE_LOCAL) {
+                        p = (top == (SC)0) ? del : ext;
+                        if (r == 0 && y == 1) p = (x == 1 || adv != 0) ? del : ext;
+                    } else p = del;
+                    SC h;
+                    int dd;
+                    cell<SC, SEM>(top, Hl[r], diag, sc, p, h, dd);
+                    diag = Hl[r];
+                    Hl[r] = h;
+                    top = h;
+                    dw = (dw >> 2) | ((uint32_t)aln_dir_to_tag(dd) << 30);
+                    if (is_local<SEM>()) {
+                        const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
+                        if (upd) { rbv[r] = h; rbx[r] = x; }
+                    }
+                }
+                hdiag = topIn;
+                bottom = Hl[R - 1];
+                if (!last && lane == 63) ring_out[x & (ALN_WG_RING - 1u)] = bottom;
+                if (SEM == ALN_CORE_LOCAL && last && hazard && (uint32_t)lane == lb) {
+                    SC hb = Hl[0];
+#pragma unroll
+                    for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Hl[r];
+                    sh.zrow[x] = (hb == (SC)0) ? 1 : 0;
+                }
+            }
+            // lane 63 has finished column k - 62: every 16 columns (and at the last one) they are published
+            if (!last && k >= 62u) {
+                const uint32_t done = k - 62u;
+                if (done <= N && ((done & 15u) == 0 || done == N) && done != 0 && lane == 63)
+                    __hip_atomic_store(sh.prod + strip, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (a.store_dirs && !dead) dirw[aln_dir_word_index(kb * SPB, (uint32_t)lane, SPB)] = dw;
+    }
+    if (dead && lane == 0) __hip_atomic_store(sh.flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+    if (is_local<SEM>()) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t y = yb + 1 + r;
+            if (y <= M && rbx[r] != 0 && better<SC, SEM>(rbv[r], y, rbx[r], bv, by, bx)) { bv = rbv[r]; by = y; bx = rbx[r]; }
+        }
+    }
+    if (last) {
+        SC hb = Hl[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Hl[r];
+        corner = O::rdlane(hb, (int)lb);
+    }
+}
+
 // ---------------------------------------------------------------- one pair, fast integer kernels
 // Core local with del != ext: the fill is speculative in the row-1 penalty ("advice") and exact once the
 // advice equals the bottom row it produced.  Pass 1 runs with all-"ext" advice and checkpoints strip 0; bottom-row zeros
@@ -724,6 +872,108 @@ void aln_fill_fast_kernel(FillArgs a)
 #endif
         }
         pair_done(a, in.lane, pair, plain);
+    }
+}
+
+// ---------------------------------------------------------------- generic kernels, one workgroup per pair (wg_strip)
+template <typename SC, int SEM, int R>
+__global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
+{
+    using O = ScOps<SC>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PairDesc &d = a.descs[a.pair];
+    aln_pair_result &res = a.results[a.pair];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6, ns = a.ns, N = d.N, M = d.M;
+    // [S][rings][advice][zrow][prod 16][cons 17][flags 4][candidates]
+    SC *S = reinterpret_cast<SC *>(smem);
+    WgShared<SC> sh;
+    sh.S = S;
+    unsigned char *p = smem + ((a.rows * a.cols * sizeof(SC) + 15u) & ~15u);
+    sh.rings = reinterpret_cast<SC *>(p); p += (size_t)ns * ALN_WG_RING * sizeof(SC);
+    const uint32_t adv_bytes = (N + 66u + 15u) & ~15u;
+    sh.advice = p; p += adv_bytes;
+    sh.zrow = p; p += adv_bytes;
+    sh.prod = reinterpret_cast<uint32_t *>(p); sh.cons = sh.prod + 20; sh.flags = sh.prod + 44; p += 64 * 4;
+    unsigned char *cand = p;                            // per wave: SC value, SC corner, by, bx (32 bytes)
+    if (d.status != ALN_OK) { skip_invalid(res, d.status, (int)threadIdx.x); return; }
+    {   // residue codes outside the matrix: the reference panics (simple/mod.rs:85,198)
+        const uint8_t *q = a.seqs + d.q_off, *t = a.seqs + d.t_off;
+        uint32_t worst_q = 0, worst_t = 0;
+        for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) worst_q = max(worst_q, (uint32_t)q[i]);
+        for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) worst_t = max(worst_t, (uint32_t)t[i]);
+        if (__syncthreads_or(worst_q >= a.cols || worst_t >= a.rows)) { skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, (int)threadIdx.x); return; }
+    }
+    const SC *gm = reinterpret_cast<const SC *>(a.matrix);
+    for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
+    const SC del = O::from_double(a.del), ext = O::from_double(a.ext);
+    const bool hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
+    for (uint32_t x = threadIdx.x; x < adv_bytes; x += blockDim.x) { sh.advice[x] = 0; sh.zrow[x] = 0; }
+    if (threadIdx.x < 64) sh.prod[threadIdx.x] = 0;     // prod, cons and flags
+    __syncthreads();
+
+    const uint32_t max_passes = a.max_passes ? a.max_passes : 4u;
+    uint32_t passes = 0;
+    bool converged = false;
+    SC bv = O::lowest(), corner = (SC)0;
+    uint32_t by = 0, bx = 0;
+    for (;;) {
+        bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : O::lowest(); by = 0; bx = 0;
+        wg_strip<SC, SEM, R>(a, d, sh, wave, wave + 1 == ns, hazard, lane, bv, by, bx, corner);
+        ++passes;
+        __syncthreads();
+        const bool aborted = sh.flags[0] != 0;
+        if (aborted) break;
+        if (!hazard) { converged = true; break; }
+        int mismatch = 0;
+        for (uint32_t x = 2 + threadIdx.x; x <= N; x += blockDim.x) {
+            const uint8_t z = sh.zrow[x - 1];
+            if (sh.advice[x] != z) { mismatch = 1; sh.advice[x] = z; }
+        }
+        converged = !__syncthreads_or(mismatch);
+        if (converged || passes >= max_passes) break;
+        if (threadIdx.x < 64) sh.prod[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    if (!converged) {                                    // strict reference order (exact for every input), one lane
+        if (threadIdx.x == 0) {
+            Wave<SC> c;
+            c.lane = 0; c.N = N; c.M = M; c.q = a.seqs + d.q_off; c.t = a.seqs + d.t_off; c.S = S; c.cols = a.cols; c.del = del; c.ext = ext;
+            c.dirw = reinterpret_cast<uint32_t *>(a.dirs + d.dir_off); c.brow = reinterpret_cast<SC *>(a.scratch); c.hmat = nullptr;
+            c.store_dirs = a.store_dirs != 0; c.pwm = false; c.bv = O::lowest(); c.by = 0; c.bx = 0; c.corner = (SC)0;
+            serial_fill_impl<SC, SEM>(c);
+            d.layout = ALN_LAYOUT_ROWMAJOR;
+            write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, (sizeof(SC) == 4 ? 1u : 0u) | 4u);
+        }
+        return;
+    }
+    // end cell: per wave a butterfly with the exact tie rule, then the waves' candidates through LDS
+    if (is_local<SEM>()) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const SC ov = O::xshfl(bv, m);
+            const uint32_t oy = (uint32_t)__shfl_xor((int)by, m), ox = (uint32_t)__shfl_xor((int)bx, m);
+            if (ox != 0 && (bx == 0 || better<SC, SEM>(ov, oy, ox, bv, by, bx))) { bv = ov; by = oy; bx = ox; }
+        }
+    }
+    if (lane == 0) {
+        double *cd = reinterpret_cast<double *>(cand + wave * 32u);
+        uint32_t *cu = reinterpret_cast<uint32_t *>(cand + wave * 32u + 16u);
+        cd[0] = (double)bv; cd[1] = (double)corner; cu[0] = by; cu[1] = bx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double best = 0.0, cor = 0.0;
+        uint32_t fy = 0, fx = 0;
+        for (uint32_t w = 0; w < ns; ++w) {
+            const double *cd = reinterpret_cast<const double *>(cand + w * 32u);
+            const uint32_t *cu = reinterpret_cast<const uint32_t *>(cand + w * 32u + 16u);
+            if (is_local<SEM>() && cu[1] != 0 && (fx == 0 || better<double, SEM>(cd[0], cu[0], cu[1], best, fy, fx))) { best = cd[0]; fy = cu[0]; fx = cu[1]; }
+            if (w + 1 == ns) cor = cd[1];
+        }
+        if (is_local<SEM>() && fx == 0) best = (SEM == ALN_LEGACY_LOCAL) ? -1.0 : -DBL_MAX;
+        d.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
+        write_result<SEM>(res, best, fy, fx, cor, N, M, passes, (sizeof(SC) == 4 ? 1u : 0u) | 4u);
     }
 }
 
@@ -1640,6 +1890,28 @@ extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_seri
 #undef ALN_SINGLE4
 #undef ALN_SINGLE
 #undef ALN_SINGLE_LAUNCH
+}
+template <typename SC, int SEM>
+static void launch_wgpipe_r(const WgArgs *a, uint32_t lds, hipStream_t s)
+{
+    const dim3 g(1), b(64 * a->ns);
+    if (a->R == 1) hipLaunchKernelGGL((aln_fill_wgpipe_kernel<SC, SEM, 1>), g, b, lds, s, *a);
+    else hipLaunchKernelGGL((aln_fill_wgpipe_kernel<SC, SEM, 2>), g, b, lds, s, *a);
+}
+template <typename SC>
+static void launch_wgpipe_sem(const WgArgs *a, uint32_t lds, hipStream_t s)
+{
+    switch (a->semantics) {
+    case ALN_CORE_GLOBAL: launch_wgpipe_r<SC, ALN_CORE_GLOBAL>(a, lds, s); break;
+    case ALN_CORE_LOCAL: launch_wgpipe_r<SC, ALN_CORE_LOCAL>(a, lds, s); break;
+    case ALN_LEGACY_GLOBAL: launch_wgpipe_r<SC, ALN_LEGACY_GLOBAL>(a, lds, s); break;
+    default: launch_wgpipe_r<SC, ALN_LEGACY_LOCAL>(a, lds, s); break;
+    }
+}
+extern "C" void aln_launch_wgpipe(const WgArgs *a, int is_int, uint32_t lds_bytes, hipStream_t s)
+{
+    if (is_int) launch_wgpipe_sem<int>(a, lds_bytes, s);
+    else launch_wgpipe_sem<double>(a, lds_bytes, s);
 }
 extern "C" void aln_launch_validate(const uint8_t *seqs, PairDesc *descs, uint32_t n_pairs, uint32_t rows, uint32_t cols, int pwm,
                                     hipStream_t s)

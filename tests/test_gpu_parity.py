@@ -123,6 +123,49 @@ def test_f64_kernels_match_oracle(orc, blosum62, sem, shape):
 
 
 @pytest.mark.parametrize("sem", SEMS)
+@pytest.mark.parametrize("shape", [(300, 600), (1000, 1000), (260, 65), (700, 1500), (2100, 2048), (16, 1024)])
+def test_generic_pair_filled_by_one_workgroup(orc, blosum62, sem, shape):
+    """A single pair of the generic kernels (real-valued matrix: every HeuristicAligner iteration; or integers forced off the fast
+    path) is filled by one workgroup, one wave per strip of 64 R rows, the strips pipelined through LDS rings (flags bit 2):
+    summary, both strings and every direction against the oracle.  R = 2 above 1024 rows; N > 256 wraps the rings."""
+    N, M = shape
+    rng = np.random.default_rng(N * 7 + M)
+    q = rng.integers(0, 20, N).astype(np.uint8)
+    t = rng.integers(0, 20, M).astype(np.uint8)
+    L = min(N, M) // 2
+    t[:L] = q[:L]                                                    # a long diagonal: the path crosses several strips
+    S = np.round(blosum62 * 0.5 + rng.normal(0, 0.05, blosum62.shape), 3)
+    legacy = sem in (_ffi.LEGACY_GLOBAL, _ffi.LEGACY_LOCAL)
+    if not legacy:                                                   # the legacy aligner is integer-only (aligner_core.rs)
+        res = check_pair(orc, sem, q, t, 11.5, 2.25, S, directions_only=True)
+        assert res is None or ((res.flags & 4) and not (res.flags & 1))
+    res = check_pair(orc, sem, q, t, 11, 11 if legacy else 2, blosum62, directions_only=True, force_generic=True)
+    assert res is None or (res.flags & 4)
+    if N * M <= 400000 and not legacy:
+        res = check_pair(orc, sem, q, t, 11, 2, blosum62, full=False, force_f64=True)
+        assert res is None or (res.flags & 4)
+
+
+@pytest.mark.parametrize("gaps", [(2, 1), (1, 2), (3, 1)])
+@pytest.mark.parametrize("shape", [(200, 200), (400, 130), (300, 700), (257, 66)])
+def test_generic_pair_one_workgroup_row1_hazard(orc, gaps, shape):
+    """The same route where the row-1 hazard bites (4 letters, +-1 scores, del != ext: exact zeros everywhere): the workgroup
+    repeats the pass with the advice it observed until it is self-consistent, or ends in the strict-order routine."""
+    N, M = shape
+    rng = np.random.default_rng(N + 31 * M + gaps[0])
+    q = rng.integers(0, 4, N).astype(np.uint8)
+    t = rng.integers(0, 4, M).astype(np.uint8)
+    S = np.where(np.eye(4) > 0, 1.0, -1.0)
+    seen = 0
+    for kw in (dict(force_generic=True), dict(force_f64=True)):
+        res = check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S, directions_only=True, **kw)
+        if res is not None:
+            assert res.flags & 4
+            seen = max(seen, res.passes & 0xff)
+    assert seen >= 1
+
+
+@pytest.mark.parametrize("sem", SEMS)
 def test_serial_order_kernel(orc, blosum62, sem):
     rng = np.random.default_rng(11)
     q = rng.integers(0, 20, 77).astype(np.uint8)
