@@ -459,7 +459,11 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         // once per iteration (heuristic/mod.rs:58-77).  Not with the H dump (the generic strip kernel writes it), not for PWM scoring.
         if (!single && !c.fast && !pwm && !c.want_h && !c.p.force_serial && !getenv("ALN_NO_WGPIPE") && n <= 16 && pc >= (1ull << 14) &&
             d.N >= 16 && d.N <= 8192 && d.M >= 65 && d.M <= 2048) {
-            const uint32_t R = d.M > 1024 ? 2u : 1u, ns = (d.M + 64 * R - 1) / (64 * R);
+            // rows per lane: about eight strips = two waves per SIMD of the one CU (measured, 1000 x 1000 f64: R = 1 1.42 ms,
+            // R = 2 1.26, R = 4 1.28; 330 x 300: 0.43 / 0.43 / 0.50)
+            uint32_t R = d.M > 1024 ? 4u : d.M > 512 ? 2u : 1u;
+            if (const char *e = getenv("ALN_WG_R")) { const uint32_t v = (uint32_t)atoi(e); if ((v == 1 || v == 2 || v == 4) && (d.M + 64 * v - 1) / (64 * v) <= 16) R = v; }
+            const uint32_t ns = (d.M + 64 * R - 1) / (64 * R);
             if (aln_wg_lds_bytes(c.rows, c.cols, c.is_int ? 4u : 8u, ns, d.N) <= 64u * 1024u) {
                 dbytes = std::max<uint64_t>(dbytes, (uint64_t)ns * aln_uniform_strip_bytes(d.N, R));
                 k.wg_pairs.push_back((uint32_t)i);

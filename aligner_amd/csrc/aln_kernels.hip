@@ -499,6 +499,12 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
     SC inchunk = (SC)0;
     uint32_t advchunk = 0;
     bool dead = false;                                 // this wave gave up waiting (the abort flag is up)
+    // the query code travels down the lanes like the boundary cell (lane 0 takes column k + 1's at step k), and the scores of
+    // the NEXT step are read from LDS while this one computes: no memory access sits in a step's dependency chain
+    int qchunk = 0, qoff = (lane == 0) ? (int)q[0] : 0;
+    SC snext[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) snext[r] = sh.S[tc[r] + qoff];
 
     uint32_t *dirw = reinterpret_cast<uint32_t *>(a.dirs + d.dir_off + (uint64_t)strip * aln_uniform_strip_bytes(N, R));
     const uint32_t nkb = (nsteps + SPB - 1) / SPB;
@@ -520,6 +526,7 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
                     if (lane == 0) __hip_atomic_store(sh.cons + strip, k + 16u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // columns <= k + 16 are in registers
                 }
                 if (SEM == ALN_CORE_LOCAL && strip == 0 && hazard) advchunk = (lane < 16 && xi <= N) ? sh.advice[xi] : 0u;
+                qchunk = (lane < 16 && xi < N) ? (int)q[xi] : 0;
                 if (!last && k + 16u > 62u + ALN_WG_RING) {
                     // the next 16 steps write columns up to k - 46 into slots the strip below must have emptied
                     const uint32_t x_max = k + 16u - 62u;
@@ -537,14 +544,19 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
             const uint32_t adv = (SEM == ALN_CORE_LOCAL && strip == 0)
                                      ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, (int)(k & 15u)) : 0u;
             const uint32_t xm1 = k - (uint32_t)lane;
+            SC scur[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) scur[r] = snext[r];
+            qoff = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qchunk, (int)(k & 15u)), qoff, 0x138, 0xf, 0xf, false);
+#pragma unroll
+            for (int r = 0; r < R; ++r) snext[r] = sh.S[tc[r] + qoff];
             if (xm1 < N) {
                 const uint32_t x = xm1 + 1;
-                const int qc = (int)q[xm1];
                 SC top = topIn, diag = hdiag;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t y = yb + 1 + r;
-                    const SC sc = sh.S[tc[r] + qc];
+                    const SC sc = scur[r];
                     SC p;
                     if (SEM == ALN_CORE_GLOBAL) p = (r == 0 && y == 1 && x == 1) ? del : ext;
                     else if (SEM == ALN_CORE_LOCAL) {
@@ -1896,7 +1908,8 @@ static void launch_wgpipe_r(const WgArgs *a, uint32_t lds, hipStream_t s)
 {
     const dim3 g(1), b(64 * a->ns);
     if (a->R == 1) hipLaunchKernelGGL((aln_fill_wgpipe_kernel<SC, SEM, 1>), g, b, lds, s, *a);
-    else hipLaunchKernelGGL((aln_fill_wgpipe_kernel<SC, SEM, 2>), g, b, lds, s, *a);
+    else if (a->R == 2) hipLaunchKernelGGL((aln_fill_wgpipe_kernel<SC, SEM, 2>), g, b, lds, s, *a);
+    else hipLaunchKernelGGL((aln_fill_wgpipe_kernel<SC, SEM, 4>), g, b, lds, s, *a);
 }
 template <typename SC>
 static void launch_wgpipe_sem(const WgArgs *a, uint32_t lds, hipStream_t s)

@@ -157,7 +157,7 @@ def small_configs(S, local_rank, stream, torch):
     q, t = workloads.c2_pair(homolog=False)
     cells = len(q) * len(t)
     w = pair_walls(_ffi.CORE_LOCAL, q, t, 11.5, 2.25, S * 0.5, reps=10)
-    out["f64_pair"] = {"workload": "the C2 pair, real-valued matrix (BLOSUM62 x 0.5, del 11.5 / ext 2.25): f64 kernels",
+    out["f64_pair"] = {"workload": "the C2 pair, real-valued matrix (BLOSUM62 x 0.5, del 11.5 / ext 2.25): f64 kernels, one workgroup per pair",
                        "aln_align_pair_wall_ms_median": round(w[len(w) // 2] * 1e3, 3), "gcups": round(cells / w[len(w) // 2] / 1e9, 3)}
     w = pair_walls(_ffi.CORE_LOCAL, q, t, 11, 2, S, reps=10, want_directions=True)
     out["pair_with_direction_matrix"] = {"workload": "the C2 pair + the (M+1) x (N+1) Direction bytes (fast kernels + unpack)",

@@ -127,7 +127,7 @@ def test_f64_kernels_match_oracle(orc, blosum62, sem, shape):
 def test_generic_pair_filled_by_one_workgroup(orc, blosum62, sem, shape):
     """A single pair of the generic kernels (real-valued matrix: every HeuristicAligner iteration; or integers forced off the fast
     path) is filled by one workgroup, one wave per strip of 64 R rows, the strips pipelined through LDS rings (flags bit 2):
-    summary, both strings and every direction against the oracle.  R = 2 above 1024 rows; N > 256 wraps the rings."""
+    summary, both strings and every direction against the oracle.  R = 2 above 512 rows, 4 above 1024; N > 256 wraps the rings."""
     N, M = shape
     rng = np.random.default_rng(N * 7 + M)
     q = rng.integers(0, 20, N).astype(np.uint8)
@@ -163,6 +163,11 @@ def test_generic_pair_one_workgroup_row1_hazard(orc, gaps, shape):
             assert res.flags & 4
             seen = max(seen, res.passes & 0xff)
     assert seen >= 1
+    # one pass allowed: the advice is not self-consistent, the workgroup's first thread runs the strict-order routine (row-major
+    # directions, walked by the batch traceback kernels)
+    res = check_pair(orc, _ffi.CORE_LOCAL, q, t, gaps[0], gaps[1], S, directions_only=True, force_f64=True, max_passes=1)
+    if res is not None and seen >= 2:
+        assert (res.flags & 4) and (res.passes & 0x80)
 
 
 @pytest.mark.parametrize("sem", SEMS)
