@@ -155,6 +155,7 @@ struct WgArgs {
     uint32_t max_passes;
     uint32_t store_dirs;
     uint8_t *scratch;         // (max(N, M) + 66) scores: the column of the strict-order routine, should the passes not converge
+    void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair (desc.h_off elements in)
 };
 #define ALN_WG_RING 256u      // entries of a hand-off ring (a strip's bottom row, by column & 255)
 __host__ __device__ inline uint32_t aln_wg_lds_bytes(uint32_t rows, uint32_t cols, uint32_t sc_size, uint32_t ns, uint32_t N)

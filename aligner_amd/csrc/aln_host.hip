@@ -456,8 +456,8 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         }
         // Generic kernels (real-valued matrix, or an integer one outside the fast path's limits): a chunk of a few pairs gives each
         // pair a whole workgroup, one wave per 64 R-row strip (<= 16 strips), instead of one wave -- the call HeuristicAligner makes
-        // once per iteration (heuristic/mod.rs:58-77).  Not with the H dump (the generic strip kernel writes it), not for PWM scoring.
-        if (!single && !c.fast && !pwm && !c.want_h && !c.p.force_serial && !getenv("ALN_NO_WGPIPE") && n <= 16 && pc >= (1ull << 14) &&
+        // once per iteration (heuristic/mod.rs:58-77).  Also with the H dump (AlignmentResult.alignment_matrix); not for PWM scoring.
+        if (!single && (!c.fast || c.want_h) && !pwm && !c.p.force_serial && !getenv("ALN_NO_WGPIPE") && n <= 16 && pc >= (1ull << 14) &&
             d.N >= 16 && d.N <= 8192 && d.M >= 65 && d.M <= 2048) {
             // rows per lane: about eight strips = two waves per SIMD of the one CU (measured, 1000 x 1000 f64: R = 1 1.42 ms,
             // R = 2 1.26, R = 4 1.28; 330 x 300: 0.43 / 0.43 / 0.50)
@@ -765,6 +765,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
         wa.results = s.results.as<aln_pair_result>(); wa.matrix = s.matrix.p; wa.rows = c.rows; wa.cols = c.cols;
         wa.del = c.p.del; wa.ext = c.p.ext; wa.semantics = c.semantics; wa.R = k.wg_r[j]; wa.ns = (d.M + 64 * wa.R - 1) / (64 * wa.R);
         wa.max_passes = c.p.max_passes; wa.store_dirs = c.store_dirs ? 1u : 0u; wa.scratch = s.scratch.as<uint8_t>();
+        wa.hmat = c.want_h ? s.hmat.p : nullptr;
         aln_launch_wgpipe(&wa, c.is_int ? 1 : 0, aln_wg_lds_bytes(c.rows, c.cols, c.is_int ? 4u : 8u, wa.ns, d.N), st);
         launches++;
         HIPCHK(hipGetLastError());

@@ -482,6 +482,7 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
     const uint32_t lb = (rows - 1) / R, rb = (rows - 1) % R;
     const SC del = O::from_double(a.del), ext = O::from_double(a.ext);
     SC *ring_in = sh.rings + (size_t)(strip ? strip - 1 : 0) * ALN_WG_RING, *ring_out = sh.rings + (size_t)strip * ALN_WG_RING;
+    SC *hmat = a.hmat ? reinterpret_cast<SC *>(a.hmat) + d.h_off : nullptr;
 
     int tc[R];
     SC Hl[R], rbv[R];
@@ -574,6 +575,7 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
                         const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
                         if (upd) { rbv[r] = h; rbx[r] = x; }
                     }
+                    if (hmat != nullptr && y <= M) hmat[(size_t)y * (N + 1) + x] = h;
                 }
                 hdiag = topIn;
                 bottom = Hl[R - 1];
@@ -921,6 +923,11 @@ __global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
     const SC del = O::from_double(a.del), ext = O::from_double(a.ext);
     const bool hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
     for (uint32_t x = threadIdx.x; x < adv_bytes; x += blockDim.x) { sh.advice[x] = 0; sh.zrow[x] = 0; }
+    if (a.hmat != nullptr) {                             // borders of the optional H dump (simple/mod.rs:55-70)
+        SC *hm = reinterpret_cast<SC *>(a.hmat) + d.h_off;
+        for (uint32_t x = threadIdx.x; x <= N; x += blockDim.x) hm[x] = border_top<SC, SEM>(x, N, del);
+        for (uint32_t y = threadIdx.x; y <= M; y += blockDim.x) hm[(size_t)y * (N + 1)] = border_left<SC, SEM>(y, M, del);
+    }
     if (threadIdx.x < 64) sh.prod[threadIdx.x] = 0;     // prod, cons and flags
     __syncthreads();
 
@@ -951,7 +958,8 @@ __global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
         if (threadIdx.x == 0) {
             Wave<SC> c;
             c.lane = 0; c.N = N; c.M = M; c.q = a.seqs + d.q_off; c.t = a.seqs + d.t_off; c.S = S; c.cols = a.cols; c.del = del; c.ext = ext;
-            c.dirw = reinterpret_cast<uint32_t *>(a.dirs + d.dir_off); c.brow = reinterpret_cast<SC *>(a.scratch); c.hmat = nullptr;
+            c.dirw = reinterpret_cast<uint32_t *>(a.dirs + d.dir_off); c.brow = reinterpret_cast<SC *>(a.scratch);
+            c.hmat = a.hmat ? reinterpret_cast<SC *>(a.hmat) + d.h_off : nullptr;
             c.store_dirs = a.store_dirs != 0; c.pwm = false; c.bv = O::lowest(); c.by = 0; c.bx = 0; c.corner = (SC)0;
             serial_fill_impl<SC, SEM>(c);
             d.layout = ALN_LAYOUT_ROWMAJOR;
