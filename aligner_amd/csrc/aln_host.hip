@@ -454,10 +454,10 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
                 k.tbmap_entries = std::max<uint64_t>(k.tbmap_entries, (uint64_t)ns * (d.N + 1) + ns + 64);
             }
         }
-        // Generic kernels (real-valued matrix, or an integer one outside the fast path's limits): a chunk of a few pairs gives each
-        // pair a whole workgroup, one wave per 64 R-row strip (<= 16 strips), instead of one wave -- the call HeuristicAligner makes
+        // Generic kernels (real-valued matrix, or an integer one outside the fast path's limits): a chunk of at most four pairs (their launches run one
+        // after the other; a larger chunk is better off with one wave per pair, all at once) gives each pair a whole workgroup, one wave per 64 R-row strip (<= 16 strips), instead of one wave -- the call HeuristicAligner makes
         // once per iteration (heuristic/mod.rs:58-77).  Also with the H dump (AlignmentResult.alignment_matrix); not for PWM scoring.
-        if (!single && (!c.fast || c.want_h) && !pwm && !c.p.force_serial && !getenv("ALN_NO_WGPIPE") && n <= 16 && pc >= (1ull << 14) &&
+        if (!single && (!c.fast || c.want_h) && !pwm && !c.p.force_serial && !getenv("ALN_NO_WGPIPE") && n <= 4 && pc >= (1ull << 14) &&
             d.N >= 16 && d.N <= 8192 && d.M >= 65 && d.M <= 2048) {
             // rows per lane: about eight strips = two waves per SIMD of the one CU (measured, 1000 x 1000 f64: R = 1 1.42 ms,
             // R = 2 1.26, R = 4 1.28; 330 x 300: 0.43 / 0.43 / 0.50)
