@@ -161,6 +161,13 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
     SC bottom = Hl[R - 1];
     SC inchunk = (SC)0;
     uint32_t advchunk = 0;
+    // The query code travels down the lanes like the boundary cell (lane 0 takes column k + 1's at step k; PWM scoring: the
+    // column index itself), and the scores of the NEXT step are read from LDS while this one computes: no memory access sits in
+    // a step's dependency chain (a byte load per step and the LDS read behind it did: 0.23 GCUPS per wave).
+    int qchunk = 0, qoff = w.pwm ? 0 : ((lane == 0) ? (int)w.q[0] : 0);
+    SC snext[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) snext[r] = w.S[tc[r] + qoff];
 
     uint32_t *dirw = w.dirw + (strip * aln_strip_bytes(N)) / 4;
     const uint32_t nkb = (nsteps + SPB - 1) / SPB;
@@ -173,6 +180,7 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
                 const uint32_t xi = k + 1 + lane;
                 if (strip > 0) inchunk = (xi <= N) ? w.brow[xi] : (SC)0;
                 if (SEM == ALN_CORE_LOCAL && strip == 0 && w.hazard) advchunk = (xi <= N) ? w.advice[xi] : 0u;
+                if (!w.pwm) qchunk = (xi < N) ? (int)w.q[xi] : 0;
             }
             SC top0;
             if (strip == 0) top0 = border_top<SC, SEM>(k + 1, N, del);
@@ -182,14 +190,20 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
             const uint32_t adv = (SEM == ALN_CORE_LOCAL && strip == 0)
                                      ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, (int)(k & 63u)) : 0u;
             const uint32_t xm1 = k - (uint32_t)lane;  // x - 1 (wraps for lanes that have not started)
+            SC scur[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) scur[r] = snext[r];
+            if (w.pwm) qoff = (int)min(xm1 + 1u, N - 1u);                                   // next step's column (lanes not started yet: any valid one)
+            else qoff = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qchunk, (int)(k & 63u)), qoff, 0x138, 0xf, 0xf, false);
+#pragma unroll
+            for (int r = 0; r < R; ++r) snext[r] = w.S[tc[r] + qoff];
             if (xm1 < N) {
                 const uint32_t x = xm1 + 1;
-                const int qc = w.pwm ? (int)xm1 : (int)w.q[xm1];
                 SC top = topIn, diag = hdiag;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const uint32_t y = yb + 1 + r;
-                    const SC s = w.S[tc[r] + qc];
+                    const SC s = scur[r];
                     SC p;
                     if (SEM == ALN_CORE_GLOBAL) {
                         // penalty is `del` for the first visited cell only (simple/mod.rs:72,88-92)
