@@ -97,6 +97,22 @@ __device__ __forceinline__ void cell(SC topH, SC leftH, SC diagH, SC s, SC p, SC
     d = dd;
 }
 
+// The same cell for the strip kernels, without a branch: the stored 2-bit tag (0 Diagonal, 1 Left, 2 Top, 3 Beginning) comes out
+// of selects (the strip loops ran ~5 scalar branches per cell before; each costs a wave ~16 cycles whether taken or not).
+template <typename SC, int SEM>
+__device__ __forceinline__ uint32_t cell_tag(SC topH, SC leftH, SC diagH, SC s, SC p, SC &h)
+{
+    using O = ScOps<SC>;
+    const SC a = topH - p, b = leftH - p, c = diagH + s;
+    SC m = O::vmax(O::vmax(a, b), c);
+    if (SEM == ALN_LEGACY_LOCAL) m = O::vmax(m, (SC)0);
+    uint32_t tag = O::eq(m, b) ? 1u : 0u;
+    tag = O::eq(m, a) ? 2u : tag;                                    // Top > Left > Diagonal
+    if (is_local<SEM>()) tag = (m == (SC)0) ? 3u : tag;              // enums.rs:37 / aligner_core.rs:214
+    h = m;
+    return tag;
+}
+
 // ---------------------------------------------------------------- per-wave state
 template <typename SC>
 struct Wave {
@@ -217,17 +233,20 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
                         p = del;
                     }
                     SC h;
-                    int d;
-                    cell<SC, SEM>(top, Hl[r], diag, s, p, h, d);
+                    const uint32_t tag = cell_tag<SC, SEM>(top, Hl[r], diag, s, p, h);
                     diag = Hl[r];
                     Hl[r] = h;
                     top = h;
-                    dw = (dw >> 2) | ((uint32_t)aln_dir_to_tag(d) << 30);   // same packing as v_alignbit in the fast path
+                    dw = (dw >> 2) | (tag << 30);                           // same packing as v_alignbit in the fast path
                     if (is_local<SEM>()) {
                         const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
-                        if (upd) { rbv[r] = h; rbx[r] = x; }
+                        rbv[r] = upd ? h : rbv[r];
+                        rbx[r] = upd ? x : rbx[r];
                     }
-                    if (w.hmat != nullptr && y <= M) w.hmat[(size_t)y * (N + 1) + x] = h;
+                }
+                if (w.hmat != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) if (yb + 1 + r <= M) w.hmat[(size_t)(yb + 1 + r) * (N + 1) + x] = Hl[r];
                 }
                 hdiag = topIn;
                 bottom = Hl[R - 1];
@@ -579,17 +598,19 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
                         if (r == 0 && y == 1) p = (x == 1 || adv != 0) ? del : ext;
                     } else p = del;
                     SC h;
-                    int dd;
-                    cell<SC, SEM>(top, Hl[r], diag, sc, p, h, dd);
+                    const uint32_t tag = cell_tag<SC, SEM>(top, Hl[r], diag, sc, p, h);
                     diag = Hl[r];
                     Hl[r] = h;
                     top = h;
-                    dw = (dw >> 2) | ((uint32_t)aln_dir_to_tag(dd) << 30);
-                    if (is_local<SEM>()) {
+                    dw = (dw >> 2) | (tag << 30);
+                    if (is_local<SEM>()) {           // (a branch here: the CU is issue-bound with its 8+ waves, and most cells update nothing)
                         const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
                         if (upd) { rbv[r] = h; rbx[r] = x; }
                     }
-                    if (hmat != nullptr && y <= M) hmat[(size_t)y * (N + 1) + x] = h;
+                }
+                if (hmat != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) if (yb + 1 + r <= M) hmat[(size_t)(yb + 1 + r) * (N + 1) + x] = Hl[r];
                 }
                 hdiag = topIn;
                 bottom = Hl[R - 1];
