@@ -835,7 +835,7 @@ __device__ __forceinline__ void set_wave_priority(uint64_t cells, uint64_t max_c
 }
 
 template <typename SC, int SEM>
-__global__ __launch_bounds__(256, 2) void aln_fill_kernel(FillArgs a)
+__global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SC *S = reinterpret_cast<SC *>(smem);
