@@ -156,6 +156,7 @@ struct WgArgs {
     uint32_t store_dirs;
     uint8_t *scratch;         // (max(N, M) + 66) scores: the column of the strict-order routine, should the passes not converge
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair (desc.h_off elements in)
+    uint32_t pwm;             // 1: position-weight-matrix scoring: S[t[y-1]][x-1], the column index instead of a query residue
 };
 #define ALN_WG_RING 256u      // entries of a hand-off ring (a strip's bottom row, by column & 255)
 __host__ __device__ inline uint32_t aln_wg_lds_bytes(uint32_t rows, uint32_t cols, uint32_t sc_size, uint32_t ns, uint32_t N)
@@ -177,6 +178,7 @@ struct TraceSingleArgs {
     uint32_t R, ns;
     uint4 *map;               // ns x (N + 1) entries {exit cx, exit cy, steps, stopped}
     uint4 *seg;               // per strip {entry cy, entry cx, tag-string offset, valid}
+    uint32_t pwm;             // PWMAligner: no duplicated seed pair (pwm/mod.rs:76-108)
 };
 
 __host__ __device__ constexpr inline uint32_t aln_spb(uint32_t R) { return R >= 5 ? 2u : R >= 3 ? 4u : 16u / R; }

@@ -535,7 +535,8 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
     bool dead = false;                                 // this wave gave up waiting (the abort flag is up)
     // the query code travels down the lanes like the boundary cell (lane 0 takes column k + 1's at step k), and the scores of
     // the NEXT step are read from LDS while this one computes: no memory access sits in a step's dependency chain
-    int qchunk = 0, qoff = (lane == 0) ? (int)q[0] : 0;
+    const bool pwm = a.pwm != 0;                       // PWM scoring: the "code" is the column index itself
+    int qchunk = 0, qoff = (lane == 0 && !pwm) ? (int)q[0] : 0;
     SC snext[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) snext[r] = sh.S[tc[r] + qoff];
@@ -560,7 +561,7 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
                     if (lane == 0) __hip_atomic_store(sh.cons + strip, k + 16u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // columns <= k + 16 are in registers
                 }
                 if (SEM == ALN_CORE_LOCAL && strip == 0 && hazard) advchunk = (lane < 16 && xi <= N) ? sh.advice[xi] : 0u;
-                qchunk = (lane < 16 && xi < N) ? (int)q[xi] : 0;
+                qchunk = (!pwm && lane < 16 && xi < N) ? (int)q[xi] : 0;
                 if (!last && k + 16u > 62u + ALN_WG_RING) {
                     // the next 16 steps write columns up to k - 46 into slots the strip below must have emptied
                     const uint32_t x_max = k + 16u - 62u;
@@ -582,6 +583,7 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
 #pragma unroll
             for (int r = 0; r < R; ++r) scur[r] = snext[r];
             qoff = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qchunk, (int)(k & 15u)), qoff, 0x138, 0xf, 0xf, false);
+            if (pwm) qoff = (int)min(xm1 + 1u, N - 1u);          // next step's column (a lane that has not started: any valid one)
 #pragma unroll
             for (int r = 0; r < R; ++r) snext[r] = sh.S[tc[r] + qoff];
             if (xm1 < N) {
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
     {   // residue codes outside the matrix: the reference panics (simple/mod.rs:85,198)
         const uint8_t *q = a.seqs + d.q_off, *t = a.seqs + d.t_off;
         uint32_t worst_q = 0, worst_t = 0;
-        for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) worst_q = max(worst_q, (uint32_t)q[i]);
+        if (!a.pwm) for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) worst_q = max(worst_q, (uint32_t)q[i]);
         for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) worst_t = max(worst_t, (uint32_t)t[i]);
         if (__syncthreads_or(worst_q >= a.cols || worst_t >= a.rows)) { skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, (int)threadIdx.x); return; }
     }
@@ -995,10 +997,10 @@ __global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
             c.lane = 0; c.N = N; c.M = M; c.q = a.seqs + d.q_off; c.t = a.seqs + d.t_off; c.S = S; c.cols = a.cols; c.del = del; c.ext = ext;
             c.dirw = reinterpret_cast<uint32_t *>(a.dirs + d.dir_off); c.brow = reinterpret_cast<SC *>(a.scratch);
             c.hmat = a.hmat ? reinterpret_cast<SC *>(a.hmat) + d.h_off : nullptr;
-            c.store_dirs = a.store_dirs != 0; c.pwm = false; c.bv = O::lowest(); c.by = 0; c.bx = 0; c.corner = (SC)0;
+            c.store_dirs = a.store_dirs != 0; c.pwm = a.pwm != 0; c.bv = O::lowest(); c.by = 0; c.bx = 0; c.corner = (SC)0;
             serial_fill_impl<SC, SEM>(c);
             d.layout = ALN_LAYOUT_ROWMAJOR;
-            write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, (sizeof(SC) == 4 ? 1u : 0u) | 4u);
+            write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, (sizeof(SC) == 4 ? 1u : 0u) | 4u, a.pwm != 0);
         }
         return;
     }
@@ -1028,7 +1030,7 @@ __global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
         }
         if (is_local<SEM>() && fx == 0) best = (SEM == ALN_LEGACY_LOCAL) ? -1.0 : -DBL_MAX;
         d.layout = ALN_LAYOUT_UNIFORM | (a.R << 8);
-        write_result<SEM>(res, best, fy, fx, cor, N, M, passes, (sizeof(SC) == 4 ? 1u : 0u) | 4u);
+        write_result<SEM>(res, best, fy, fx, cor, N, M, passes, (sizeof(SC) == 4 ? 1u : 0u) | 4u, a.pwm != 0);
     }
 }
 
@@ -1700,7 +1702,7 @@ extern "C" __global__ void aln_tb_single_chain_kernel(TraceSingleArgs a)
         }
     }
     res.start_y = cy; res.start_x = cx;
-    res.aln_len = off + 1;
+    res.aln_len = off + (a.pwm ? 0u : 1u);              // + the duplicated seed pair (none for the PWM aligner)
 }
 
 // one block per strip: stages the window its segment starts in, then one thread re-walks the segment and writes the
@@ -1747,9 +1749,10 @@ extern "C" __global__ __launch_bounds__(1024) void aln_tb_single_expand_kernel(T
     const uint8_t *__restrict__ t = a.seqs + d.t_off;
     const uint32_t cap = d.N + d.M + 2;
     uint8_t *__restrict__ qa = a.tb + d.tb_off;
-    uint8_t *__restrict__ ta = qa + cap;
+    uint8_t *__restrict__ ta = qa + (a.pwm ? 4ull : 1ull) * cap;     // PWM: 4-byte column numbers instead of query residues (pwm/mod.rs:86-101)
+    uint32_t *__restrict__ numbered = reinterpret_cast<uint32_t *>(qa);
     const uint8_t *__restrict__ ops = a.tags + d.tag_off;
-    const uint32_t len = res.aln_len - 1u;
+    const uint32_t len = res.aln_len - (a.pwm ? 0u : 1u);
     const uint32_t per = (len + 1023u) / 1024u;
     const uint32_t lo = min(len, tid * per), hi = min(len, lo + per);
     uint32_t dy = 0, dx = 0;
@@ -1771,10 +1774,11 @@ extern "C" __global__ __launch_bounds__(1024) void aln_tb_single_expand_kernel(T
     for (uint32_t j = lo; j < hi; ++j) {
         const uint32_t tag = ops[len - 1 - j];
         px += (tag != 2u); py += (tag != 1u);
-        qa[j] = (tag == 2u) ? a.blank : q[px - 1];
+        if (a.pwm) numbered[j] = (tag == 2u) ? 0u : px;
+        else qa[j] = (tag == 2u) ? a.blank : q[px - 1];
         ta[j] = (tag == 1u) ? a.blank : t[py - 1];
     }
-    if (tid == 0) {
+    if (tid == 0 && !a.pwm) {
         qa[len] = q[res.end_x - 1];                     // the duplicated seed pair
         ta[len] = t[res.end_y - 1];
     }
