@@ -154,14 +154,16 @@ struct WgArgs {
     uint32_t R, ns;           // rows per lane (1 or 2), strips = waves of the workgroup (<= 16)
     uint32_t max_passes;
     uint32_t store_dirs;
-    uint8_t *scratch;         // (max(N, M) + 66) scores: the column of the strict-order routine, should the passes not converge
+    uint8_t *scratch;         // (max(N, M) + 66) scores: row 1 as the pass computed it (adopt_advice_checked); then the column of the
+                              // strict-order routine, should the passes not converge
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair (desc.h_off elements in)
     uint32_t pwm;             // 1: position-weight-matrix scoring: S[t[y-1]][x-1], the column index instead of a query residue
 };
 #define ALN_WG_RING 256u      // entries of a hand-off ring (a strip's bottom row, by column & 255)
 __host__ __device__ inline uint32_t aln_wg_lds_bytes(uint32_t rows, uint32_t cols, uint32_t sc_size, uint32_t ns, uint32_t N)
 {
-    return ((rows * cols * sc_size + 15u) & ~15u) + ns * ALN_WG_RING * sc_size + 2u * ((N + 66u + 15u) & ~15u) + 64u * 4u + ns * 32u;
+    return ((rows * cols * sc_size + 15u) & ~15u) + ns * ALN_WG_RING * sc_size + 3u * ((N + 66u + 15u) & ~15u) + 64u * 4u + ns * 32u +
+           (N <= 2048u ? (((N + 66u) * sc_size + 15u) & ~15u) : 0u);      // row 1 of the pass: in LDS for short queries, else in the scratch
 }
 
 // Parallel traceback of one large pair (uniform-R layout): per strip and entry column an "exit map", then a short

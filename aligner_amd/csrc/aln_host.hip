@@ -544,7 +544,9 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
     // path: at most (max_len + 63) / 2 + 4 blocks)
     const uint64_t zrow_bytes = std::max<uint64_t>(adv_bytes, (4ull * (((uint64_t)max_len + 63) / 2 + 8) + 63) & ~63ull);
     k.zrow_bytes = (uint32_t)zrow_bytes;
-    k.scratch_stride = (uint64_t)k.cascade_rows * brow_bytes + adv_bytes + zrow_bytes + ck_bytes;
+    // generic kernels: row 1 as the pass computed it (values + direction tags), for adopt_advice_checked
+    const uint64_t row1_bytes = c.fast ? 0 : brow_bytes + adv_bytes;
+    k.scratch_stride = (uint64_t)k.cascade_rows * brow_bytes + adv_bytes + zrow_bytes + ck_bytes + row1_bytes;
     k.lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
     k.prof_stride = 0;
     if (c.fast && !pwm) { k.prof_stride = cols * 64u * ALN_FULL_R; k.lds_bytes += 4u * k.prof_stride; }
@@ -1062,7 +1064,7 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
             const uint64_t nrows = (c.fast && c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext) ? ALN_CASCADE_ROWS : 1u;
             const uint64_t stride = nrows * (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull) +
                                     std::max<uint64_t>((mlen + 66 + 63) & ~63ull, (4 * ((mlen + 63) / 2 + 8) + 63) & ~63ull) +
-                                    (c.fast ? (uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 : 0);
+                                    (c.fast ? (uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 : (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull));
             need.scratch = std::max(need.scratch, (uint64_t)max_cus * 4 * 4 * stride);
         }
     }

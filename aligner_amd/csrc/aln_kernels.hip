@@ -125,6 +125,8 @@ struct Wave {
     uint32_t *dirw;           // this pair's direction region
     SC *brow;                 // boundary row scratch (N + 66)
     uint8_t *advice, *zrow;   // row-1 penalty advice / observed bottom-row zeros
+    SC *row1;                 // hazard pairs: H[1][x] and its direction tag as the pass computed them (adopt_advice_checked)
+    uint8_t *row1tag;
     SC *hmat;                 // optional H dump for this pair
     bool hazard;
     bool store_dirs;          // false: score-only
@@ -243,6 +245,7 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
                         rbv[r] = upd ? h : rbv[r];
                         rbx[r] = upd ? x : rbx[r];
                     }
+                    if (SEM == ALN_CORE_LOCAL && r == 0 && strip == 0 && w.hazard && lane == 0) { w.row1[x] = h; w.row1tag[x] = (uint8_t)tag; }
                 }
                 if (w.hmat != nullptr) {
 #pragma unroll
@@ -356,6 +359,32 @@ __device__ __forceinline__ bool adopt_advice(uint8_t *advice, const uint8_t *zro
     return !__any(mismatch);
 }
 
+// The same, and is the pass already the answer?  Only row 1's penalties depend on the advice.  If, at every column whose advice
+// bit changes, cell (1, x) recomputed with the new penalty -- from the pass's own H[1][x-1] -- keeps its value and its direction,
+// then (induction over the reference's visiting order) the fill under the new advice is cell for cell the fill just made: its
+// bottom row is the observed one, the new advice is self-consistent, and no second pass is needed.  With real-valued scores
+// the bottom row's exact zeros fall anywhere and nearly every pair changes some bit; two thirds of them change no cell.
+template <typename SC, int SEM>
+__device__ __forceinline__ bool adopt_advice_checked(uint8_t *advice, const uint8_t *zrow, const SC *row1, const uint8_t *row1tag, const SC *S,
+                                                     uint32_t cols, const uint8_t *q, const uint8_t *t, bool pwm, SC del, SC ext, uint32_t N, int tid,
+                                                     int nthreads, int &same_cells)
+{
+    int mismatch = 0, moved = 0;
+    const int t0 = (int)t[0] * (int)cols;
+    for (uint32_t x = 2 + (uint32_t)tid; x <= N; x += (uint32_t)nthreads) {
+        const uint8_t z = zrow[x - 1];
+        if (advice[x] != z) {
+            mismatch = 1;
+            SC h;
+            const uint32_t tag = cell_tag<SC, SEM>((SC)0, row1[x - 1], (SC)0, S[t0 + (pwm ? (int)(x - 1) : (int)q[x - 1])], z ? del : ext, h);
+            if (!(h == row1[x]) || tag != (uint32_t)row1tag[x]) moved = 1;
+            advice[x] = z;
+        }
+    }
+    same_cells = !moved;
+    return !mismatch;
+}
+
 // the same for the fast path, whose last strip records the direction words of the lane that owns row M (one per block):
 // H[M][x] == 0 <=> tag 3
 __device__ __forceinline__ bool adopt_advice_zdw(uint8_t *advice, const uint32_t *zdw, uint32_t N, uint32_t M, int lane,
@@ -456,8 +485,11 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
             ++passes;
             __threadfence_block();
             if (!w.hazard) { converged = true; break; }
-            uint32_t lf;
-            converged = adopt_advice(w.advice, w.zrow, N, lane, lf);
+            int same = 0;
+            const bool unchanged = adopt_advice_checked<SC, SEM>(w.advice, w.zrow, w.row1, w.row1tag, w.S, w.cols, w.q, w.t, w.pwm, w.del, w.ext,
+                                                                 N, lane, 64, same);
+            __threadfence_block();
+            converged = !__any(!unchanged) || !__any(!same);
         } while (!converged && passes < max_passes);
     }
     uint32_t layout = ALN_LAYOUT_SKEW;
@@ -495,7 +527,8 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
 template <typename SC> struct WgShared {
     const SC *S;
     SC *rings;
-    uint8_t *advice, *zrow;
+    uint8_t *advice, *zrow, *row1tag;
+    SC *row1;                           // global scratch: H[1][x] of the pass
     uint32_t *prod, *cons, *flags;      // flags[0] abort, flags[1] advice mismatch
 };
 
@@ -609,6 +642,7 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
                         const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
                         if (upd) { rbv[r] = h; rbx[r] = x; }
                     }
+                    if (SEM == ALN_CORE_LOCAL && r == 0 && strip == 0 && hazard && lane == 0) { sh.row1[x] = h; sh.row1tag[x] = (uint8_t)tag; }
                 }
                 if (hmat != nullptr) {
 #pragma unroll
@@ -854,6 +888,8 @@ __global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
     w.brow = reinterpret_cast<SC *>(sc);
     w.advice = sc + brow_bytes;
     w.zrow = sc + brow_bytes + adv_bytes;                 // a.zrow_bytes >= adv_bytes
+    w.row1 = reinterpret_cast<SC *>(w.zrow + a.zrow_bytes);
+    w.row1tag = reinterpret_cast<uint8_t *>(w.row1) + brow_bytes;
     w.S = S;
     w.cols = a.cols;
     w.del = ScOps<SC>::from_double(a.del);
@@ -945,8 +981,11 @@ __global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
     const uint32_t adv_bytes = (N + 66u + 15u) & ~15u;
     sh.advice = p; p += adv_bytes;
     sh.zrow = p; p += adv_bytes;
+    sh.row1tag = p; p += adv_bytes;
+    sh.row1 = reinterpret_cast<SC *>(a.scratch);
     sh.prod = reinterpret_cast<uint32_t *>(p); sh.cons = sh.prod + 20; sh.flags = sh.prod + 44; p += 64 * 4;
     unsigned char *cand = p;                            // per wave: SC value, SC corner, by, bx (32 bytes)
+    if (N <= 2048u) sh.row1 = reinterpret_cast<SC *>(cand + ns * 32u);      // (aln_wg_lds_bytes)
     if (d.status != ALN_OK) { skip_invalid(res, d.status, (int)threadIdx.x); return; }
     {   // residue codes outside the matrix: the reference panics (simple/mod.rs:85,198)
         const uint8_t *q = a.seqs + d.q_off, *t = a.seqs + d.t_off;
@@ -981,12 +1020,11 @@ __global__ __launch_bounds__(1024) void aln_fill_wgpipe_kernel(WgArgs a)
         const bool aborted = sh.flags[0] != 0;
         if (aborted) break;
         if (!hazard) { converged = true; break; }
-        int mismatch = 0;
-        for (uint32_t x = 2 + threadIdx.x; x <= N; x += blockDim.x) {
-            const uint8_t z = sh.zrow[x - 1];
-            if (sh.advice[x] != z) { mismatch = 1; sh.advice[x] = z; }
-        }
-        converged = !__syncthreads_or(mismatch);
+        int same = 0;
+        const bool unchanged = adopt_advice_checked<SC, SEM>(sh.advice, sh.zrow, sh.row1, sh.row1tag, S, a.cols, a.seqs + d.q_off, a.seqs + d.t_off,
+                                                             a.pwm != 0, del, ext, N, (int)threadIdx.x, (int)blockDim.x, same);
+        const int need = __syncthreads_or(!unchanged), moved = __syncthreads_or(!same);
+        converged = !need || !moved;                     // the advice stands, or changing it moves no cell of row 1
         if (converged || passes >= max_passes) break;
         if (threadIdx.x < 64) sh.prod[threadIdx.x] = 0;
         __syncthreads();
