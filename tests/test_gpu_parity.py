@@ -170,6 +170,35 @@ def test_generic_pair_one_workgroup_row1_hazard(orc, gaps, shape):
         assert (res.flags & 4) and (res.passes & 0x80)
 
 
+def test_generic_kernels_accept_a_pass_whose_new_advice_moves_no_cell_of_row_1(orc, blosum62):
+    """Real-valued scores: the bottom row has exact zeros at arbitrary columns, so the all-"ext" advice of the first pass is
+    wrong somewhere in nearly every pair -- but only row 1 reads it.  When the corrected advice leaves every cell of row 1
+    as the pass computed it, the pass is the answer (adopt_advice_checked) and is not repeated: single pairs (one workgroup
+    per pair) and a batch (one wave per pair) against the oracle, and both outcomes -- one pass, two passes -- must occur."""
+    rng = np.random.default_rng(2718)
+    S = blosum62 * 0.5
+    one = two = 0
+    pairs = []
+    for i in range(10):
+        N, M = int(rng.integers(300, 900)), int(rng.integers(300, 900))
+        q = rng.integers(0, 20, N).astype(np.uint8)
+        t = rng.integers(0, 20, M).astype(np.uint8)
+        pairs.append((q, t))
+        ref = orc.align(_ffi.CORE_LOCAL, q, t, 11.5, 2.25, S, want_matrices=True)
+        zeros = bool((ref["H"][M, 1:N] == 0).any())                  # the first pass's advice is not the final one
+        res = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11.5, 2.25, S, directions_only=True)
+        assert res.flags & 4
+        if zeros and (res.passes & 0x7f) == 1:
+            one += 1
+        if (res.passes & 0x7f) >= 2:
+            two += 1
+    assert one >= 1 and two >= 1, (one, two)
+    b = PairBatch.from_pairs(pairs * 3)                              # 30 pairs: the batch kernel
+    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11.5, 2.25, S)
+    p = got.results["passes"] & 0x7f
+    assert (p == 1).any() and (p >= 2).any()
+
+
 @pytest.mark.parametrize("sem", SEMS)
 def test_serial_order_kernel(orc, blosum62, sem):
     rng = np.random.default_rng(11)
