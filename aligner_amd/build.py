@@ -12,6 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libaligner_hip.so")
 SOURCES = ["aln_kernels.hip", "aln_host.hip"]
+# aln_kernels.hip is compiled as several translation units side by side (-DALN_TU=<mask of its ALN_PART_* families>): the fast
+# core-local batch kernel alone is half of the compile time
+KERNEL_UNITS = [("generic", 1), ("fast_cl", 2), ("fast_rest", 4), ("single", 8), ("tb", 16)]
 HEADERS = ["aln_device.h", "aln_fast.h", "aln_single_unit.inc", os.path.join("..", "..", "include", "aligner_hip.h")]
 # host-only helper of the synthetic workloads (splitmix64 residues; aligner_amd/workloads.py only LOADS it)
 SYNTH_LIB = os.path.join(LIBDIR, "libaln_synth.so")
@@ -38,16 +41,52 @@ def build_synth(force=False):
     return SYNTH_LIB
 
 
+# tests/abi_harness.c: include/aligner_hip.h compiled as C99 and linked against the library (the check that the header itself is a
+# usable C interface; run on the GPU box by tests/test_gpu_parity.py)
+HARNESS_SRC = os.path.join(HERE, "..", "tests", "abi_harness.c")
+HARNESS = os.path.join(HERE, "..", "tests", "bin", "abi_harness")
+
+
+def build_harness(force=False):
+    src, out = os.path.abspath(HARNESS_SRC), os.path.abspath(HARNESS)
+    hdr = os.path.join(HERE, "..", "include", "aligner_hip.h")
+    if force or not os.path.exists(out) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB)) > os.path.getmtime(out):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        tmp = out + ".tmp%d" % os.getpid()
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-std=c99", "-Wall", "-Werror", "-I", os.path.join(HERE, "..", "include"), src, "-o", tmp,
+                               "-L", LIBDIR, "-laligner_hip", "-Wl,-rpath,$ORIGIN/../../aligner_amd/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+        os.replace(tmp, out)
+    return out
+
+
 def build(force=False, remarks=False):
+    lib = _build_lib(force, remarks)
+    build_harness(force)
+    return lib
+
+
+def _build_lib(force=False, remarks=False):
     build_synth(force)
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
     # ALN_CXXFLAGS: extra flags for an instrumented build (-DALN_STAMPS: per-pair time stamps for tools/tail_timeline.py)
-    cmd = [hipcc] + FLAGS + os.environ.get("ALN_CXXFLAGS", "").split() + (["-Rpass-analysis=kernel-resource-usage"] if remarks else []) + \
-        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    subprocess.check_call(cmd)
+    base = [hipcc] + [f for f in FLAGS if f != "-shared"] + os.environ.get("ALN_CXXFLAGS", "").split() + \
+        (["-Rpass-analysis=kernel-resource-usage"] if remarks else [])
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(base + ["-DALN_TU=%d" % mask, "-c", os.path.join(CSRC, "aln_kernels.hip"), "-o", os.path.join(objdir, "aln_kernels_%s.o" % name)])
+            for name, mask in KERNEL_UNITS]
+    jobs.append(base + ["-c", os.path.join(CSRC, "aln_host.hip"), "-o", os.path.join(objdir, "aln_host.o")])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+        for rc, cmd in zip(pool.map(subprocess.call, jobs), jobs):
+            if rc != 0:
+                raise subprocess.CalledProcessError(rc, cmd)
+    tmp = LIB + ".tmp%d" % os.getpid()
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[-1] for j in jobs] + ["-o", tmp])
+    os.replace(tmp, LIB)
     return LIB
 
 

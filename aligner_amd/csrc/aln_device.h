@@ -35,7 +35,9 @@
 #define ALN_STRIP_ROWS (64 * ALN_FULL_R)   // rows per full strip
 #define ALN_LAYOUT_SKEW 0u      // 512-row strips, R = 8 except the last strip (batch kernels)
 #define ALN_LAYOUT_ROWMAJOR 1u  // serial-order fallback
-#define ALN_LAYOUT_UNIFORM 2u   // every strip has 64*R rows, R in bits 8..15 (single-pair kernel)
+#define ALN_LAYOUT_UNIFORM 2u   // every strip has 64*R rows, R in bits 8..15 (single-pair kernel; walked by the aln_tb_single_* kernels)
+#define ALN_LAYOUT_UBATCH 3u    // the same uniform-R strips written by the batch kernel (a cooperative re-fill, see CoopRec): walked by
+                                // the batch traceback like the skewed layout
 
 struct PairDesc {
     uint64_t q_off, t_off;   // into seqs
@@ -81,7 +83,68 @@ struct FillArgs {
     uint32_t zrow_bytes;      // bytes of the bottom-row record in each wave's scratch (bytes per column, or one direction word per block)
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
     uint8_t blank;
+    // cooperative passes (fast kernels, see CoopRec): control words, hint rings and one record per fill wave; null = off
+    uint32_t *coop;
+    uint32_t n_descs;                // descriptors behind `descs` (a claimed strip names its pair by index)
+    uint32_t coop_waves;             // fill waves = claim words = records (the claim words are padded to a multiple of 64)
+    uint32_t salt;                   // tag salt of this launch (aln_coop_tag)
+    uint32_t coop_tail;              // first passes are opened for the pairs from this queue position on (the last ones taken; earlier
+                                     // pairs finish while every wave still has pairs of its own to take)
+    uint32_t coop_linger;            // 1: waves that find the queue dry stay and take strips until every pair has finished
+    uint32_t coop_debug;             // testing (ALN_COOP_DEBUG): bit 0 first passes are not opened; bit 1 no hints are posted (the owner
+                                     // claims every strip of an open pass itself); bit 2 re-fills keep the skewed layout
 };
+
+// ---- cooperative passes of the fast batch kernel
+// One wave per pair leaves the tail of a small batch to whoever got the last large pair -- or a pair whose row-1 advice did not
+// survive and has to be filled a second time (0.8 % of C5; the 8-way shard ended 1.2x after its ideal time because of them).  A
+// pass over a pair is a chain of strips; strip s + 1 only needs the bottom row of strip s, 64 columns at a time, so the strips of
+// ONE pass can run on different waves as a pipeline.  The wave that owns the pair opens its record (CoopRec, one per fill wave),
+// runs strip 0 itself and then claims further strips like everybody else.
+//   claim word   one per fill wave, in a dense array: {sequence number, kind (0 closed, 1 lazy, 2 urgent), strips, strips left}.
+//                A claim is a compare-and-swap that takes `left` down by one (contended by the few waves that found this record,
+//                and the sequence number makes a stale value fail); strips are claimed in order, and a claimed strip is being run
+//                by a resident wave, so the wait of strip s for strip s - 1's columns always ends.
+//   finding work two counters of unclaimed strips, urgent (re-fills: the pair is late already) and lazy (first passes).  A wave
+//                between two pairs reads the urgent one -- one load of a line its L2 holds -- and looks for the record only when
+//                it is not zero: first in a short log of the last urgent opens, then by scanning the claim words, 64 per load.
+//                A wave that finds the queue dry does the same for both kinds.  No queue of hints: a queue's head is one word
+//                every idle wave fights for (measured: 3000 waves popping 20 000 entries by compare-and-swap took 0.6 s).
+//   hand-over    bottom rows, progress words, candidates and the record's fields are stored write-through (agent-scope atomics)
+//                and read the same way (cdna_hip_programming.md, Guideline 16); the direction quads of such a kernel are
+//                stored write-through as well (FastIn::wt_dirs).
+// Every wait is bounded and raises the record's abort word; the owner then redoes the pass alone.
+#define ALN_COOP_MAX_NS 64u
+// Everything one wave hands to another is either inside a word that only atomic read-modify-writes touch (the claim word) or an
+// 8-byte GRANULE {value, tag}, stored and loaded whole (agent-scope atomics = write-through / past L1): the reader polls until the
+// tag is the one it expects, so neither the order in which stores become visible nor a copy of an older pass in some cache can be
+// taken for the data (cdna_hip_programming.md, Guideline 16, form R2).  Tag of strip s of a pass: aln_coop_tag(salt, seq) | s --
+// salt: a per-launch number of the slot that owns the scratch rows (10 bits; the host clears the rows when it wraps), seq: the
+// owner wave's count of multi-strip passes in this launch (12 bits; the wave clears its rows when it wraps).  Bit 31 set and
+// bit 30 clear: no T value (|T| < 2^28) looks like a tag, whatever else a row was used for.
+struct CoopRec {
+    unsigned long long pairg;                      // {pair, tag | 127}
+    unsigned long long cand[ALN_COOP_MAX_NS][5];   // per strip {., tag | strip}: end-cell candidate bv, by, bx (T form), corner, status (1: gave up)
+};
+__host__ __device__ inline uint32_t aln_coop_tag(uint32_t salt, uint32_t seq) { return 0x80000000u | ((salt & 0x3ffu) << 19) | ((seq & 0xfffu) << 7); }
+// claim word: bits 0..6 strips left, 7..13 strips, 14..15 kind (0: only the owner claims), 16 strip 0's bottom row keeps a row of
+// its own, 17..19 rows per lane of uniform strips (0: the skewed layout), 20..31 seq
+#define ALN_COOP_KIND_LAZY 1u
+#define ALN_COOP_KIND_URGENT 2u
+__host__ __device__ inline uint32_t aln_coop_word(uint32_t seq, uint32_t R, uint32_t own, uint32_t kind, uint32_t ns, uint32_t left)
+{
+    return ((seq & 0xfffu) << 20) | (R << 17) | (own << 16) | (kind << 14) | (ns << 7) | left;
+}
+// FillArgs::coop: control words, then the claim words (one per fill wave, padded to a multiple of 64), then the records
+#define ALN_COOP_UOPEN 0         // unclaimed strips of urgent passes
+#define ALN_COOP_LOPEN 1         // unclaimed strips of lazy passes
+#define ALN_COOP_ULOGW 2         // urgent opens so far = write index of the log
+#define ALN_COOP_FINISHED 3      // pairs whose summary is written (the four words above are what an idle wave polls: one 16-byte load)
+#define ALN_COOP_HELPED 5        // diagnostics: strips run by a wave that does not own the pair
+#define ALN_COOP_ABORTS 6
+#define ALN_COOP_SCANS 7         // diagnostics: scans of the claim words
+#define ALN_COOP_ULOG 32         // .. 47: the waves (+ 1) that opened the last 16 urgent passes
+#define ALN_COOP_CTL_WORDS 256u   // (128 ..: diagnostics)
 
 // one large pair, one wave per strip, strips pipelined through granule rows in HBM/L2
 struct SingleArgs {
@@ -116,7 +179,7 @@ struct SingleArgs {
 
 // strip 0 of a hazard pair checkpoints its lane state at steps max(16, one quad), then doubling, up to 512
 #define ALN_CK_SLOTS 6
-#define ALN_CASCADE_ROWS 2u
+#define ALN_CASCADE_ROWS 3u
 #define ALN_CK_FIRST 16u
 
 struct TraceArgs {
@@ -222,10 +285,21 @@ __host__ __device__ inline uint64_t aln_rowmajor_bytes(uint32_t N, uint32_t M)
 {
     return (uint64_t)(M + 1) * ((N + 4) / 4);
 }
+// rows per lane of a cooperative re-fill's uniform strips: at most eight strips up to 2048 rows; 0 = keep the skewed layout
+__host__ __device__ inline uint32_t aln_coop_uniform_r(uint32_t M)
+{
+    if (M <= 64u || M > 2048u) return 0u;
+    return M <= 512u ? 1u : M <= 1024u ? 2u : 4u;
+}
 __host__ __device__ inline uint64_t aln_dir_bytes(uint32_t N, uint32_t M)
 {
     uint64_t a = (uint64_t)aln_num_strips(M) * aln_strip_bytes(N);
     uint64_t b = aln_rowmajor_bytes(N, M);
     uint64_t m = a > b ? a : b;
+    const uint32_t R = aln_coop_uniform_r(M);
+    if (R) {
+        const uint64_t c = (uint64_t)((M + 64u * R - 1u) / (64u * R)) * aln_uniform_strip_bytes(N, R);
+        m = c > m ? c : m;
+    }
     return (m + 255) & ~(uint64_t)255;
 }

@@ -127,14 +127,17 @@ struct FastIn {
     uint8_t *prof;            // LDS, this wave's profile
     int nd4, ne4;             // -4*del, -4*ext
     uint32_t *dirw;
-    int *brow_in, *brow_out;  // batch kernels: the row above this strip / this strip's bottom row (one row used in place; for hazard
+    unsigned long long *brow_in, *brow_out;   // batch kernels: the row above this strip / this strip's bottom row, as 8-byte granules
+                              // {T value, tag of the strip that wrote it} (see row_tag below) (one row used in place; for hazard
                               // pairs strip 0's bottom row keeps a row of its own: the repair compares against it)
     uint8_t *advice, *zrow;
     int *ckpt;
     bool hazard;
     bool adv_any;             // single-pair kernel: the advice may hold non-zero bytes (second and later passes)
     bool store_dirs;          // false: score-only (the packed directions are not written)
-    bool wt_dirs;             // batch kernels: direction quads are stored write-through (a walk kernel on another XCD reads them while this kernel runs)
+    bool wt_dirs;             // batch kernels: direction quads are stored write-through (a walk kernel on another XCD reads them while this kernel
+                              // runs; with cooperative passes a re-fill's strips, run on other XCDs, rewrite the first pass's lines: a plain store would
+                              // leave them dirty in two L2s, and which write-back wins is anybody's guess)
     bool pwm;                 // position-weight-matrix scoring (batch kernels only)
     const uint32_t *pwm_words;// per column: int8 scores 4*s - 2 of residues 0..3
     uint32_t ck_stop;         // single-pair kernel: the step at which pass 0 saves the strip's lane state (ck_mode 1) / the repair run
@@ -149,6 +152,13 @@ struct FastIn {
     uint32_t *ring_in, *ring_out;   // single-pair kernel: LDS rings (ALN_RING entries, aligned to their size) when the
                                     // strip above / below is a wave of this workgroup, else null (granule rows)
     uint32_t *abort_flag;
+    // batch kernels: where a strip sits in the pair (skewed layout: 512 rows, aln_strip_bytes; a cooperative re-fill's uniform
+    // layout: 64 R rows, aln_uniform_strip_bytes)
+    uint32_t strip_rows, strip_q16;
+    // batch kernels: tag of this pass's granules without the strip number (row_tag); every boundary cell, every bottom-row record
+    // word and every end-cell candidate a strip hands on carries tag_base | strip, unique for (launch, owner's pass, strip): the
+    // reader polls until it sees that tag, whoever ran the strip and whatever copies of older passes caches still hold
+    uint32_t tag_base;
 };
 
 // The lane's running end-cell candidate (T form) + outcome flags; threaded through the strips by value.
@@ -198,7 +208,7 @@ struct FastStrip {
     const uint32_t N;
     uint32_t lb, rb, yb;
     uint32_t chunk0;           // first step of the tracker's current chunk
-    uint32_t cchg;             // repair: last column whose bottom-row cell changed (lane 63)
+    uint32_t cchg;             // repair: a column of this lane's whose bottom-row cell changed (0: none)
     bool zsel_on, brow_bad, aborted;
     int Tl[R], rbv[R];
     int hdiag, bottom, qoff, inchunk, qchunk, outq;
@@ -233,14 +243,53 @@ struct FastStrip {
     }
 
     // batch kernels: next 64 columns of the row above this strip (T form), one per lane
-    __device__ __forceinline__ int load_boundary(uint32_t xi) { return (xi < N) ? in.brow_in[xi + 1] : 2; }
+    // batch kernels: the next 64 columns of the row above this strip, one per lane.  The strip above may be running right now on
+    // another wave (a cooperative pass): every granule carries the tag of the strip that wrote it, and the load is repeated until
+    // all 64 carry the expected one (bounded; giving up poisons the pass, which the pair's owner then redoes alone).
+    __device__ __forceinline__ int fetch_above(uint32_t xi)
+    {
+        const uint32_t want = in.tag_base | (strip - 1u);
+        const unsigned long long *p = in.brow_in + xi + 1;
+        unsigned long long g = 0;
+        uint32_t spins = 0;
+        for (;;) {
+            if (xi < N) g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(xi >= N || (uint32_t)(g >> 32) == want)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 17)) { aborted = true; break; }
+        }
+        return (xi < N) ? (int)(uint32_t)g : 2;
+    }
+    // batch kernels: lane 63's newest bottom cell enters a 64-deep lane shift register every step (DPP wave_shl:1, as in the
+    // single-pair kernel), and every 64 steps the wave stores 64 consecutive columns of its bottom row with ONE coalesced store of
+    // 8-byte granules (a store per step by lane 63 alone was 64 partial-line writes instead of four whole lines).  Before step k
+    // lane l holds column k - 126 + l.  Repair run of strip 0: nothing is stored, the columns are compared with the row the
+    // checkpointed pass wrote (a cell that comes out different ends the repair).
+    __device__ __forceinline__ void flush_below(uint32_t k, uint32_t beyond)
+    {
+        const uint32_t x = k - 126u + (uint32_t)lane;
+        if (x - 1u < N && x > beyond) {
+            unsigned long long *p = in.brow_out + x;
+            if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 2) {
+                if ((int)(uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != outq) cchg = x;
+            } else
+                __hip_atomic_store(p, ((unsigned long long)(in.tag_base | strip) << 32) | (uint32_t)outq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the columns the shift register still holds after `ksteps` steps (end of the strip, or the checkpoint at which a repair ends)
+    __device__ __forceinline__ void flush_tail(uint32_t ksteps)
+    {
+        const uint32_t kb_last = ((ksteps - 1u) / 64u) * 64u;          // the last boundary flush_below ran at (from step 64 on)
+        flush_below(ksteps, kb_last >= 64u ? kb_last - 63u : 0u);
+    }
 
     template <bool MASKED>
     __device__ __forceinline__ void step(const uint32_t k)
     {
         if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
-            if (!FIRST && !SINGLE) inchunk = load_boundary(xi);
+            if (!SINGLE && !LAST && k >= 64u) flush_below(k, 0u);
+            if (!FIRST && !SINGLE) inchunk = fetch_above(xi);
             if (SEM == ALN_CORE_LOCAL && FIRST && in.hazard) advchunk = (xi < N) ? in.advice[xi + 1] : 0u;
             if (!SINGLE) qchunk = (xi + 1 < N) ? (PWM ? (int)in.pwm_words[xi + 1] : (int)in.q[xi + 1] * (64 * RP)) : 0;
         }
@@ -313,15 +362,9 @@ struct FastStrip {
             }
             hdiag = topIn;
             bottom = Tl[R - 1];
-            if (!SINGLE && !last && lane == 63) {
-                const uint32_t x = xm1 + 1;
-                // repair (strip 0): the row is the checkpointed pass's; a cell that comes out different ends the repair
-                if (FIRST && SEM == ALN_CORE_LOCAL && in.ck_mode == 2) { if (in.brow_out[x] != bottom) cchg = x; }
-                else in.brow_out[x] = bottom;
-            }
         }
         // bottom row to the strip below: lane 63's newest cell enters a 64-deep lane shift register (DPP wave_shl:1)
-        if (SINGLE && !LAST) outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);
+        if (!LAST) outq = __builtin_amdgcn_update_dpp(bottom, outq, 0x130, 0xf, 0xf, false);
     }
 
     // single-pair kernel: after step k lanes 48..63 hold the bottom-row cells of columns c-15..c, c = k - 63; one
@@ -395,7 +438,12 @@ struct FastStrip {
     // Beginning <=> H == 0): one dword per block instead of a select chain and a byte store per step
     __device__ __forceinline__ void store_zdw(uint32_t block)
     {
-        if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) reinterpret_cast<uint32_t *>(in.zrow)[block] = dw;
+        if (SEM == ALN_CORE_LOCAL && zsel_on && (uint32_t)lane == lb) {
+            if (SINGLE) reinterpret_cast<uint32_t *>(in.zrow)[block] = dw;
+            else   // a granule like the boundary cells: read by the pair's owner, which may be another wave
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(in.zrow) + block, ((unsigned long long)(in.tag_base | strip) << 32) | dw,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 
     // ---- steady state of the single-pair core-local kernel (ASMPATH): whole quads through the generated asm loop.
@@ -641,7 +689,7 @@ struct FastStrip {
     __device__ __forceinline__ FastOut run(FastOut o)
     {
         const uint32_t M = in.M;
-        const uint32_t y0 = strip * STRIP_ROWS;
+        const uint32_t y0 = strip * (SINGLE ? STRIP_ROWS : in.strip_rows);
         const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
         const uint32_t L = (rows + R - 1) / R;
         const uint32_t nsteps = (SINGLE && !LAST) ? N + 63 : N + L - 1;
@@ -700,7 +748,7 @@ struct FastStrip {
 
         // directions: four blocks per lane per 16-byte store (aln_device.h); all segment ends are whole quads
         uint4 *dirq = reinterpret_cast<uint4 *>(in.dirw) +
-                      (size_t)strip * (SINGLE ? (size_t)(aln_uniform_strip_bytes(N, R) / 16) : (size_t)(aln_strip_bytes(N) / 16)) + lane;
+                      (size_t)strip * (SINGLE ? (size_t)(aln_uniform_strip_bytes(N, R) / 16) : (size_t)in.strip_q16) + lane;
         const uint32_t nkb = aln_strip_blocks(nsteps, SPB);
         // ramp-up (some lanes not started) | steady state (every lane active, no exec masking) | ramp-down
         // (block counts: a lane's 64th step is in block 63 / SPB; segment ends are whole quads)
@@ -776,7 +824,8 @@ struct FastStrip {
                         if (__any(tracker)) fold(o, 0);
                         o.repaired = true;
                         o.ck_slot = slot;
-                        o.c_out = (uint32_t)__builtin_amdgcn_readlane((int)cchg, 63);
+                        if (!LAST) flush_tail(kb * SPB);       // the columns still in the shift register are compared too
+                        o.c_out = __any(cchg != 0u) ? 1u : 0u;
                     }
                     return o;
                 }
@@ -792,6 +841,7 @@ struct FastStrip {
             }
         }
         if (SINGLE && !LAST && !(ASMPATH && !FIRST)) publish(nkb * SPB - 1);     // the last (up to 15) columns (the asm publishes after every unit)
+        if (!SINGLE && !LAST && !(ckmode && in.ck_mode == 2)) flush_tail(nkb * SPB);
         o.brow_bad = o.brow_bad || brow_bad;
         o.aborted = o.aborted || aborted;
         if (ckmode && in.ck_mode == 2) return o;         // ran out of checkpoints: the caller escalates to a full pass
@@ -806,24 +856,34 @@ struct FastStrip {
     }
 };
 
-// Batch kernels: every strip but the last has 512 rows (R = 8); the last one picks R by its row count.
-template <int SEM, bool PWM>
-__device__ __forceinline__ FastOut fast_strip(const FastIn &in, FastOut o, uint32_t s, bool last, int R)
+// Batch kernels, skewed layout: every strip but the last has 512 rows (R = 8), the last one picks R by its row count.  A
+// cooperative re-fill (core local, no PWM scoring) instead cuts the pair into uniform strips of 64 R rows, R = 1, 2 or 4.
+// Strip 0 and the strips below it are separate functions: a call site instantiates only the strips it can reach.
+#define ALN_STRIP_CASE(RR, FIRSTV, LASTV) case RR: { FastStrip<SEM, RR, false, FIRSTV, LASTV, PWM> f(in, s); return f.run(o); }
+template <int SEM, bool PWM, bool FIRSTV>
+__device__ __forceinline__ FastOut fast_strip_of(const FastIn &in, FastOut o, uint32_t s, bool last, int R)
 {
     if (!last) {
-        if (s == 0) { FastStrip<SEM, ALN_FULL_R, false, true, false, PWM> f(in, s); return f.run(o); }
-        FastStrip<SEM, ALN_FULL_R, false, false, false, PWM> f(in, s);
+        if constexpr (SEM == ALN_CORE_LOCAL && !PWM) {
+            switch (R) {
+            ALN_STRIP_CASE(1, FIRSTV, false) ALN_STRIP_CASE(2, FIRSTV, false) ALN_STRIP_CASE(4, FIRSTV, false)
+            default: break;
+            }
+        }
+        FastStrip<SEM, ALN_FULL_R, false, FIRSTV, false, PWM> f(in, s);
         return f.run(o);
     }
-#define ALN_LAST_STRIP(RR) case RR: if (s == 0) { FastStrip<SEM, RR, false, true, true, PWM> f(in, s); return f.run(o); } \
-                          else { FastStrip<SEM, RR, false, false, true, PWM> f(in, s); return f.run(o); }
     switch (R) {
-    ALN_LAST_STRIP(1) ALN_LAST_STRIP(2) ALN_LAST_STRIP(3) ALN_LAST_STRIP(4) ALN_LAST_STRIP(5) ALN_LAST_STRIP(6) ALN_LAST_STRIP(7)
-    default: if (s == 0) { FastStrip<SEM, 8, false, true, true, PWM> f(in, s); return f.run(o); }
-             else { FastStrip<SEM, 8, false, false, true, PWM> f(in, s); return f.run(o); }
+    ALN_STRIP_CASE(1, FIRSTV, true) ALN_STRIP_CASE(2, FIRSTV, true) ALN_STRIP_CASE(3, FIRSTV, true) ALN_STRIP_CASE(4, FIRSTV, true)
+    ALN_STRIP_CASE(5, FIRSTV, true) ALN_STRIP_CASE(6, FIRSTV, true) ALN_STRIP_CASE(7, FIRSTV, true)
+    default: { FastStrip<SEM, 8, false, FIRSTV, true, PWM> f(in, s); return f.run(o); }
     }
-#undef ALN_LAST_STRIP
 }
+#undef ALN_STRIP_CASE
+template <int SEM, bool PWM>
+__device__ __forceinline__ FastOut fast_strip_first(const FastIn &in, FastOut o, bool last, int R) { return fast_strip_of<SEM, PWM, true>(in, o, 0, last, R); }
+template <int SEM, bool PWM>
+__device__ __forceinline__ FastOut fast_strip_next(const FastIn &in, FastOut o, uint32_t s, bool last, int R) { return fast_strip_of<SEM, PWM, false>(in, o, s, last, R); }
 
 // butterfly reduction of the per-lane end-cell candidates with the exact tie rule
 template <int SEM>

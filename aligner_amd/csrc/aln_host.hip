@@ -131,7 +131,7 @@ static void pin_free(PinBuf &b)
 struct Slot {
     bool pooled = true;       // pool slots keep some slack when they grow; a staged batch's private slot is sized exactly
     DevBuf seqs, descs, order, counter, walked, dirs, results, tb, tags, scratch, matrix, pwm_words, hmat;
-    DevBuf granules, advice1, cand, ctrl, tbmap, unpack, repair;
+    DevBuf granules, advice1, cand, ctrl, tbmap, unpack, repair, coop;
     PinBuf h_meta;            // descs + order + matrix + pwm words (small, truly asynchronous H2D)
     PinBuf h_in, h_out;       // fallback staging: sequences gathered from scattered offsets / strings for a foreign tb layout
     hipStream_t stream = nullptr;
@@ -139,6 +139,10 @@ struct Slot {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_done = nullptr, ev_fill = nullptr;
     uint32_t epoch = 0;
     bool walked_clean = false;
+    // fast batch kernels: the boundary rows in `scratch` hold tagged granules (aln_coop_tag); the tag's salt counts this slot's
+    // launches, and the rows are cleared whenever the buffer is new or the salt's 10 bits wrap
+    uint32_t salt = 0;
+    bool scratch_clean = false;
 };
 
 // one GPU of a context: its properties and its slot pool
@@ -172,7 +176,7 @@ static void slot_destroy(Slot *s)
 {
     if (!s) return;
     DevBuf *d[] = {&s->seqs, &s->descs, &s->order, &s->counter, &s->walked, &s->dirs, &s->results, &s->tb, &s->tags, &s->scratch,
-                   &s->matrix, &s->pwm_words, &s->hmat, &s->granules, &s->advice1, &s->cand, &s->ctrl, &s->tbmap, &s->unpack, &s->repair};
+                   &s->matrix, &s->pwm_words, &s->hmat, &s->granules, &s->advice1, &s->cand, &s->ctrl, &s->tbmap, &s->unpack, &s->repair, &s->coop};
     for (DevBuf *b : d) dev_free(*b);
     pin_free(s->h_meta); pin_free(s->h_in); pin_free(s->h_out);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -373,6 +377,10 @@ struct Chunk {
     uint64_t scratch_stride = 0, granule_bytes = 0, tbmap_entries = 0, granule_stride_max = 0;
     size_t counter_bytes = 256;
     bool overlap = false;             // walk waves beside the fill (in-kernel overlapped traceback)
+    // cooperative passes of the fast batch kernel (CoopRec, aln_device.h): hint ring capacities, bytes of the control block
+    bool coop = false;
+    uint32_t coop_tail = 0;
+    uint64_t coop_bytes = 0;
     // sequences: either one contiguous span of the caller's buffer, or gathered pair by pair into pinned staging
     bool seq_direct = true;
     uint64_t seq_lo = 0, seq_span = 0;
@@ -412,7 +420,35 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
     }
 
     // ---- routing + HBM layout.  A pair goes to the single-pair kernel (one wave per strip, strips pipelined across
-    // CUs) when it is large, or when the chunk is too small to fill the chip with one wave per pair.
+    // CUs) when it is large, or when the chunk is too small to fill the chip with one wave per pair -- unless the chunk holds
+    // so many such pairs that the batch kernel, whose waves share the strips of a pair (cooperative passes), is through with all
+    // of them sooner than the single-pair route, which takes them one after the other.  Estimates (measured rates): the
+    // single-pair route fills at ~60 GCUPS plus ~0.2 ms of launches and traceback per pair; in the batch kernel a wave fills at
+    // ~0.85 GCUPS with the chip full (2.6 TCUPS at most), and the pipeline of a pair's strips takes (N + 63 + 170 (strips - 1))
+    // steps of ~0.55 us.
+    const bool coop_on = c.fast && !getenv("ALN_NO_COOP");
+    bool big_to_single = true;
+    if (coop_on && !pwm && !env_off) {
+        double t_single = 0, cells_all = 0, cells_small = 0, strips_all = 0, strips_small = 0, lat_all = 0, lat_small = 0;
+        size_t n_big = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const PairDesc &d = k.descs[i];
+            if (d.status != ALN_OK) continue;
+            const double pc = (double)d.N * d.M, st = (double)aln_num_strips(d.M);
+            const double lat = ((double)d.N + 63.0 + 170.0 * (st - 1.0)) * 0.55e-6;
+            const bool big = d.N >= 64 && d.M >= 128 && (pc >= (double)(1ull << 24) || (n <= 16 && pc >= (double)(1ull << 18)));
+            cells_all += pc; strips_all += st; lat_all = std::max(lat_all, lat);
+            if (big) { t_single += pc / 60e9 + 0.2e-3; ++n_big; }
+            else { cells_small += pc; strips_small += st; lat_small = std::max(lat_small, lat); }
+        }
+        const double waves = (double)ctx->cus * 12.0;
+        auto t_batch = [&](double cells, double strips, double lat) {
+            if (cells <= 0) return 0.0;
+            return std::max(std::max(cells / 2.6e12, lat), cells / (std::min(strips, waves) * 0.85e9));
+        };
+        if (n_big) big_to_single = t_single + t_batch(cells_small, strips_small, lat_small) <= t_batch(cells_all, strips_all, lat_all);
+        if (const char *e = getenv("ALN_BIG_TO_SINGLE")) big_to_single = atoi(e) != 0;
+    }
     uint64_t dir_total = 0, tb_total = 0, tag_total = 0, hm_total = 0, cells = 0;
     uint32_t max_len = 1;
     for (size_t i = 0; i < n; ++i) {
@@ -429,7 +465,8 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         const uint64_t pc = (uint64_t)d.N * d.M;
         cells += pc;
         max_len = std::max(max_len, std::max(d.N, d.M));
-        bool single = c.fast && !pwm && !env_off && d.N >= 64 && d.M >= 128 && (pc >= (1ull << 24) || (n <= 16 && pc >= (1ull << 18)));
+        bool single = c.fast && !pwm && !env_off && d.N >= 64 && d.M >= 128 && (pc >= (1ull << 24) || (n <= 16 && pc >= (1ull << 18))) &&
+                      (big_to_single || aln_num_strips(d.M) > ALN_COOP_MAX_NS);
         uint64_t dbytes = aln_dir_bytes(d.N, d.M);
         if (single) {
             // rows per lane: two above ~2500 rows (measured, fill + traceback: 3000 x 3000 0.59 ms against 0.62 with one, 4000 x 4000
@@ -532,22 +569,38 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
             k.counter_bytes = 256 + 4ull * k.n_small;
         }
     }
+    // Cooperative passes: waves without a pair of their own take strips of other waves' pairs, so a batch with fewer pairs than
+    // resident waves still gets as many waves as it has strips
+    k.coop = coop_on && k.n_small != 0;
+    if (k.coop) {
+        uint64_t strips = 0;
+        for (size_t j = 0; j < k.n_small; ++j) { const PairDesc &d = k.descs[k.order[j]]; if (d.status == ALN_OK) strips += aln_num_strips(d.M); }
+        const uint32_t resident = (uint32_t)ctx->cus * 3u;
+        if (!k.overlap) k.grid = std::max(k.grid, (uint32_t)std::min<uint64_t>(resident, (strips + 3) / 4));
+        // first passes give strips away only for the last pairs of the queue: two per resident wave (the pairs that can still be
+        // running when the queue is dry); ALN_COOP_TAIL overrides (pairs from the end)
+        uint64_t tail = 2ull * resident * 4u;
+        if (const char *e = getenv("ALN_COOP_TAIL")) tail = strtoull(e, nullptr, 10);
+        k.coop_tail = (uint32_t)(k.n_small > tail ? k.n_small - tail : 0);
+    }
     if (const char *e = getenv("ALN_FILL_WGS")) k.grid = std::max(1u, std::min(k.grid, (uint32_t)atoi(e)));   // experiments: fewer resident fill waves
-    const uint64_t sc_size = c.is_int ? 4 : 8;
+    if (k.coop) k.coop_bytes = 4ull * (ALN_COOP_CTL_WORDS + (((uint64_t)k.grid * 4 + 63) & ~63ull)) + (uint64_t)k.grid * 4 * sizeof(CoopRec);
+    const uint64_t sc_size = (c.is_int && !c.fast) ? 4 : 8;          // fast kernels: 8-byte granules {T value, tag}
     const uint64_t brow_bytes = (((uint64_t)max_len + 66) * sc_size + 63) & ~63ull;
     const uint64_t adv_bytes = ((uint64_t)max_len + 66 + 63) & ~63ull;
     // fast path, core local with del != ext: strip 0's bottom row keeps a row of its own and strip 0 checkpoints its lane state
     // (18 ints x 64 lanes per checkpoint): the localized repair of the row-1 hazard, do_pair_fast
-    k.cascade_rows = (c.fast && c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext) ? ALN_CASCADE_ROWS : 1u;
+    // (fast kernels: a strip never writes the row it reads -- two rows; hazard pairs: strip 0's bottom row keeps one more to itself)
+    k.cascade_rows = (c.fast && c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext) ? ALN_CASCADE_ROWS : (c.fast ? 2u : 1u);
     const uint64_t ck_bytes = c.fast ? (uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 : 0;
     // bottom-row record: one byte per column (generic kernels) or one direction dword per block of the last strip (fast
     // path: at most (max_len + 63) / 2 + 4 blocks)
-    const uint64_t zrow_bytes = std::max<uint64_t>(adv_bytes, (4ull * (((uint64_t)max_len + 63) / 2 + 8) + 63) & ~63ull);
+    const uint64_t zrow_bytes = std::max<uint64_t>(adv_bytes, ((c.fast ? 8ull : 4ull) * (((uint64_t)max_len + 63) / 2 + 8) + 63) & ~63ull);
     k.zrow_bytes = (uint32_t)zrow_bytes;
     // generic kernels: row 1 as the pass computed it (values + direction tags), for adopt_advice_checked
     const uint64_t row1_bytes = c.fast ? 0 : brow_bytes + adv_bytes;
     k.scratch_stride = (uint64_t)k.cascade_rows * brow_bytes + adv_bytes + zrow_bytes + ck_bytes + row1_bytes;
-    k.lds_bytes = (uint32_t)(((uint64_t)rows * cols * sc_size + 15) & ~15ull);
+    k.lds_bytes = (uint32_t)(((uint64_t)rows * cols * (c.is_int ? 4 : 8) + 15) & ~15ull);
     k.prof_stride = 0;
     if (c.fast && !pwm) { k.prof_stride = cols * 64u * ALN_FULL_R; k.lds_bytes += 4u * k.prof_stride; }
     return ALN_OK;
@@ -556,7 +609,7 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
 // upper bounds over the chunks of a pipelined call: a slot is sized for the largest chunk the first time it is touched, so no
 // buffer grows (hipFree + hipMalloc stall every stream) in the middle of the pipeline
 struct Need {
-    uint64_t seq_span = 0, n = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, scratch = 0;
+    uint64_t seq_span = 0, n = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, scratch = 0, coop = 0;
 };
 
 // device buffers of a slot for this chunk (grow-only; nothing happens once the pool is warm)
@@ -574,11 +627,13 @@ static int slot_ensure(Slot &s, const Call &c, const Chunk &k, const Need *need 
         ENS(tb, need->tb_bytes);
         ENS(tags, need->tag_bytes);
         ENS(scratch, need->scratch);
+        if (need->coop) ENS(coop, need->coop);
     }
     ENS(seqs, k.seq_span + 64);
     ENS(descs, k.n * sizeof(PairDesc));
     ENS(order, k.n * sizeof(uint32_t));
     ENS(counter, k.counter_bytes);
+    if (k.coop) ENS(coop, k.coop_bytes);
     if (k.overlap) {
         const size_t before = s.walked.cap;
         ENS(walked, 4ull * k.n);
@@ -591,7 +646,12 @@ static int slot_ensure(Slot &s, const Call &c, const Chunk &k, const Need *need 
     ENS(results, k.n * sizeof(aln_pair_result));
     ENS(tb, k.tb_bytes);
     ENS(tags, k.tag_bytes);
-    ENS(scratch, std::max<uint64_t>((uint64_t)k.grid * 4 * k.scratch_stride, k.wg_pairs.empty() ? 0 : ((uint64_t)k.max_len + 66) * 8));
+    {
+        const size_t before = s.scratch.cap;
+        const void *before_p = s.scratch.p;
+        ENS(scratch, std::max<uint64_t>((uint64_t)k.grid * 4 * k.scratch_stride, k.wg_pairs.empty() ? 0 : ((uint64_t)k.max_len + 66) * 8));
+        if (s.scratch.cap != before || s.scratch.p != before_p) s.scratch_clean = false;
+    }
     if (!k.wg_pairs.empty()) ENS(tbmap, k.tbmap_entries * 16);
     ENS(matrix, (uint64_t)c.rows * c.cols * (c.is_int ? 4 : 8));
     if (c.pwm && c.fast) ENS(pwm_words, (uint64_t)c.cols * 4);
@@ -676,6 +736,11 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     if (fill_launches) *fill_launches = 0;
     if (k.n == 0) return ALN_OK;
     if (k.n_small) HIPCHK(hipMemsetAsync(s.counter.p, 0, k.counter_bytes, st));     // the batch kernel's work queue
+    if (k.n_small && k.coop) HIPCHK(hipMemsetAsync(s.coop.p, 0, k.coop_bytes, st)); // counters, claim words (zero = nothing to claim), records
+    if (k.n_small && c.fast) {
+        s.salt = (s.salt + 1u) & 0x3ffu;
+        if (!s.scratch_clean || s.salt == 0u) { HIPCHK(hipMemsetAsync(s.scratch.p, 0, s.scratch.cap, st)); s.scratch_clean = true; }
+    }
     // residue codes outside the matrix: the batch fill kernels check the pairs they take; the single-pair route reads the status
     // from the descriptor, so its pairs are checked by a kernel of their own in front
     if (!k.single_pairs.empty())
@@ -694,6 +759,10 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     fa.pwm = c.pwm ? 1u : 0u;
     fa.pwm_words = s.pwm_words.as<uint32_t>();
     fa.hmat = c.want_h ? s.hmat.p : nullptr; fa.blank = c.p.blank_code;
+    fa.n_descs = (uint32_t)k.n;
+    fa.coop = k.coop ? s.coop.as<uint32_t>() : nullptr; fa.coop_waves = k.grid * 4u; fa.coop_tail = k.coop_tail; fa.salt = s.salt;
+    { const char *e = getenv("ALN_COOP_LINGER"); fa.coop_linger = e ? (uint32_t)atoi(e) : 1u; }
+    { const char *e = getenv("ALN_COOP_DEBUG"); fa.coop_debug = e ? (uint32_t)atoi(e) : 0u; }
     if (fill_after) HIPCHK(hipStreamWaitEvent(st, fill_after, 0));
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     uint32_t launches = 0;
@@ -812,6 +881,25 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     return ALN_OK;
 }
 
+// diagnostics (ALN_COOP_STATS): the control words of the cooperative passes after a run
+static void coop_stats_slot(Slot &s, const Chunk &k)
+{
+    if (k.coop && getenv("ALN_COOP_STATS")) {
+        uint32_t w[256] = {0};
+        if (hipMemcpy(w, s.coop.p, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (w[14]) {
+                fprintf(stderr, "coop: %u strips left rows without their tag; the first: N %u, strip %u of %u, R %u, own %u, open %u; columns (tag found):", w[14], w[16], (w[15] >> 4), w[17] >> 8,
+                        w[15] & 15u, w[17] & 1u, (w[17] >> 1) & 1u);
+                for (int i = 0; i < 40 && w[128 + i]; ++i) fprintf(stderr, " %u(%#x)", w[128 + i], w[192 + i]);
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "coop: urgent passes %u, unclaimed strips now %d urgent %d lazy, finished %u, strips helped %u, scans %u, aborted passes %u, spins waiting for strips to finish %u; "
+                    "strips that gave up waiting for the row above %u, owners that gave up waiting for a strip %u, bottom-row records not found %u, pair granules not found %u\n",
+                    w[ALN_COOP_ULOGW], (int)w[ALN_COOP_UOPEN], (int)w[ALN_COOP_LOPEN], w[ALN_COOP_FINISHED], w[ALN_COOP_HELPED], w[ALN_COOP_SCANS], w[ALN_COOP_ABORTS], w[9],
+                    w[10], w[11], w[12], w[13]);
+        }
+    }
+}
 // D2H of one chunk on `st`, then a stream sync: summaries into results[first ..], strings into tb_buf.  When the caller's
 // tb_off is the documented cumulative layout the chunk's strings are ONE span of tb_buf and are copied there directly;
 // any other layout goes through pinned staging and one memcpy per string.
@@ -833,6 +921,7 @@ static int slot_download(Slot &s, const Call &c, const Chunk &k, hipStream_t st,
         }
     }
     HIPCHK(hipStreamSynchronize(st));
+    coop_stats_slot(s, k);
     if (want && !direct) {
         const uint8_t *h = s.h_out.as<uint8_t>();
         for (size_t i = 0; i < k.n; ++i) {
@@ -1040,7 +1129,7 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
     job.c = &c; job.seqs = seqs; job.q_off = q_off; job.q_len = q_len; job.t_off = t_off; job.t_len = t_len;
     job.results = results; job.tb_buf = tb_buf; job.tb_off = tb_off; job.ranges = &ranges;
     {   // upper bounds over the chunks: every slot is sized once, before the pipeline runs
-        const uint64_t sc = c.is_int ? 4 : 8;
+        const uint64_t sc = (c.is_int && !c.fast) ? 4 : 8;       // fast kernels: 8-byte granules (chunk_plan)
         int max_cus = 0;
         for (const DevCtx *d : ctx->devs) max_cus = std::max(max_cus, d->cus);
         Need &need = job.need;
@@ -1054,6 +1143,7 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
                 if (N && M && c.store_dirs) dirs += aln_dir_bytes((uint32_t)N, (uint32_t)M);
                 if (N && M) mlen = std::max(mlen, std::max(N, M));
             }
+            if (c.fast) need.coop = std::max<uint64_t>(need.coop, 4ull * (ALN_COOP_CTL_WORDS + (uint64_t)max_cus * 16 + 64) + (uint64_t)max_cus * 16 * sizeof(CoopRec));
             const uint64_t span = hi > lo ? ((hi - lo) <= 2 * sum + 65536 ? hi - lo : sum) : 0;
             need.seq_span = std::max(need.seq_span, span);
             need.n = std::max<uint64_t>(need.n, r.second);
@@ -1061,9 +1151,9 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
             need.tb_bytes = std::max(need.tb_bytes, tb);
             need.tag_bytes = std::max(need.tag_bytes, tags);
             // per wave: boundary row, advice, bottom-row record, checkpoints (chunk_plan)
-            const uint64_t nrows = (c.fast && c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext) ? ALN_CASCADE_ROWS : 1u;
+            const uint64_t nrows = (c.fast && c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext) ? ALN_CASCADE_ROWS : (c.fast ? 2u : 1u);
             const uint64_t stride = nrows * (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull) +
-                                    std::max<uint64_t>((mlen + 66 + 63) & ~63ull, (4 * ((mlen + 63) / 2 + 8) + 63) & ~63ull) +
+                                    std::max<uint64_t>((mlen + 66 + 63) & ~63ull, ((c.fast ? 8 : 4) * ((mlen + 63) / 2 + 8) + 63) & ~63ull) +
                                     (c.fast ? (uint64_t)ALN_CK_SLOTS * 18 * 64 * 4 : (((mlen + 66) * sc + 63) & ~63ull) + ((mlen + 66 + 63) & ~63ull));
             need.scratch = std::max(need.scratch, (uint64_t)max_cus * 4 * 4 * stride);
         }
@@ -1158,11 +1248,14 @@ extern "C" int aln_batch_run(aln_batch *b, void *stream)
     return st;
 }
 
+static void coop_stats(aln_batch *b) { coop_stats_slot(*b->slot, b->k); }
+
 extern "C" int aln_batch_sync(aln_batch *b)
 {
     if (!b) return ALN_ERR_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipStreamSynchronize(b->last_stream ? b->last_stream : b->slot->stream));
+    coop_stats(b);
     return ALN_OK;
 }
 
@@ -1180,6 +1273,7 @@ extern "C" int aln_batch_timing(aln_batch *b, double *fill_ms, double *tb_ms, ui
         HIPCHK(hipEventElapsedTime(&t, ev[1], ev[2]));
         fs += f; ts += t;
     }
+    coop_stats(b);
     if (fill_ms) *fill_ms = fs / runs;
     if (tb_ms) *tb_ms = ts / runs;
     if (fill_launches) *fill_launches = b->fill_launches;

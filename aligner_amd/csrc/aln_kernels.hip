@@ -24,6 +24,17 @@
 
 #include "aln_device.h"
 
+// The file is compiled as several translation units in parallel (aligner_amd/build.py: -DALN_TU=<mask>), each instantiating one
+// family of kernels together with the launch helpers that name them; the templates themselves are seen by every unit.
+#define ALN_PART_GENERIC 1     // generic fill kernels (int32 without the profile, f64), one-workgroup route, validation
+#define ALN_PART_FAST_CL 2     // fast integer batch kernel, core local
+#define ALN_PART_FAST_REST 4   // fast integer batch kernels: core local with PWM scoring, core global, legacy
+#define ALN_PART_SINGLE 8      // single-pair (strip-pipelined) route
+#define ALN_PART_TB 16         // traceback + direction unpack
+#ifndef ALN_TU
+#define ALN_TU 31
+#endif
+
 namespace {
 
 constexpr int D_TOP = 0, D_LEFT = 1, D_DIAG = 2, D_BEG = 3;
@@ -386,23 +397,33 @@ __device__ __forceinline__ bool adopt_advice_checked(uint8_t *advice, const uint
 }
 
 // the same for the fast path, whose last strip records the direction words of the lane that owns row M (one per block):
-// H[M][x] == 0 <=> tag 3
-__device__ __forceinline__ bool adopt_advice_zdw(uint8_t *advice, const uint32_t *zdw, uint32_t N, uint32_t M, int lane,
-                                                 uint32_t &last_flip)
+// H[M][x] == 0 <=> tag 3.  Ru = 0: the skewed layout (512-row strips, the last one by aln_pick_r); else uniform strips of 64 Ru rows.
+// The record is a row of granules {direction word, tag of the strip that wrote it}: in a cooperative pass that was another wave.
+// bad: a granule never showed the expected tag (cannot be: the strip's candidate, stored after its record has drained, has been seen).
+__device__ __forceinline__ bool adopt_advice_zdw(uint8_t *advice, const unsigned long long *zdw, uint32_t ztag, uint32_t N, uint32_t M, uint32_t Ru,
+                                                 int lane, uint32_t &last_flip, bool &bad)
 {
-    const uint32_t ns = aln_num_strips(M), rows_last = M - (ns - 1) * ALN_STRIP_ROWS;
-    const uint32_t R = (uint32_t)aln_pick_r(rows_last), lb = (rows_last - 1) / R, rb = (rows_last - 1) % R, spb = aln_spb(R);
-    int mismatch = 0;
+    const uint32_t srows = Ru ? 64u * Ru : (uint32_t)ALN_STRIP_ROWS;
+    const uint32_t ns = (M + srows - 1u) / srows, rows_last = M - (ns - 1) * srows;
+    const uint32_t R = Ru ? Ru : (uint32_t)aln_pick_r(rows_last), lb = (rows_last - 1) / R, rb = (rows_last - 1) % R, spb = aln_spb(R);
+    int mismatch = 0, lost = 0;
     uint32_t lf = 0;
     for (uint32_t x = 2 + lane; x <= N; x += 64) {
         const uint32_t k = x - 2 + lb;                                  // wave step of cell (M, x - 1)
-        const uint8_t z = ((zdw[k / spb] >> aln_dir_bitpos(k, rb, lb, N, (int)R)) & 3u) == 3u ? 1 : 0;
+        unsigned long long g = __hip_atomic_load(zdw + k / spb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t spins = 0; (uint32_t)(g >> 32) != ztag && spins < 100000u; ++spins) {
+            __builtin_amdgcn_s_sleep(2);
+            g = __hip_atomic_load(zdw + k / spb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if ((uint32_t)(g >> 32) != ztag) lost = 1;
+        const uint8_t z = (((uint32_t)g >> aln_dir_bitpos(k, rb, lb, N, (int)R)) & 3u) == 3u ? 1 : 0;
         if (advice[x] != z) { mismatch = 1; advice[x] = z; }
         if (z != 0) lf = x;
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) lf = max(lf, (uint32_t)__shfl_xor((int)lf, m));
     last_flip = lf;
+    bad = __any(lost) != 0;
     __threadfence_block();
     return !__any(mismatch);
 }
@@ -684,25 +705,180 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
     }
 }
 
+__device__ __forceinline__ void skip_invalid(aln_pair_result &res, int status, int lane)
+{
+    if (lane == 0) {
+        res.f = 0.0; res.score = 0.0; res.end_y = res.end_x = res.start_y = res.start_x = 0;
+        res.aln_len = 0; res.status = status == ALN_PRE_EMPTY_OK ? ALN_OK : status; res.passes = 0; res.flags = 0;
+    }
+}
+
+
+// The SIMD's instruction arbiter is not fair: among waves of equal priority the oldest wave issues first, and with three
+// VALU-bound waves per SIMD the youngest gets ~13 % of the issue slots (measured: 1.5 / 0.9 / 0.35 GCUPS for the three).
+// Throughput does not care, the tail of a small batch does: a large pair taken at t = 0 by a youngest wave was still in its
+// first pass when everything else had finished.  So the wave's priority follows the size of its pair (thirds of the
+// queue's largest pair): in the LPT order this is "oldest pair first" -- a large pair is never starved by the smaller pairs
+// the older waves of its SIMD move on to.
+__device__ __forceinline__ void set_wave_priority(uint64_t cells, uint64_t max_cells)
+{
+    if (3 * cells > 2 * max_cells) __builtin_amdgcn_s_setprio(2);          // 3 belongs to the walk kernel that runs beside the fill
+    else if (3 * cells > max_cells) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 // ---------------------------------------------------------------- one pair, fast integer kernels
 // Core local with del != ext: the fill is speculative in the row-1 penalty ("advice") and exact once the
 // advice equals the bottom row it produced.  Pass 1 runs with all-"ext" advice and checkpoints strip 0; bottom-row zeros
 // sit next to the left border, so a mismatch is repaired by re-running only the leading columns of strip 0 until its
 // lane state rejoins the checkpoint (localized repair); anything else escalates to full re-fills and finally to the
 // strict reference-order routine.
-// what a wave's scratch holds for the fast kernels (aln_fill_fast_kernel sets it up)
+// what a wave's scratch holds for the fast kernels: [boundary rows][advice][bottom-row record][checkpoint sets]
 struct FastScratch {
-    int *rows;                // boundary rows, `nrows` of them, row_ints apart
-    uint32_t row_ints, nrows;
+    unsigned long long *rows; // boundary rows of granules, `nrows` of them, row_elems apart
+    uint32_t row_elems, nrows;
     int *ckpt;                // checkpoint sets, one per row, ck_ints apart
     uint32_t ck_ints;
+    uint8_t *advice, *zrow;
 };
-
-template <int SEM, bool PWM>
-__device__ __forceinline__ bool do_pair_fast(FastIn in, const FastScratch &fs, const FillArgs &a, PairDesc &desc, aln_pair_result &res, int del, int ext)
+__device__ __forceinline__ FastScratch fast_scratch(const FillArgs &a, uint32_t wave)
 {
-    const int lane = in.lane;
+    uint8_t *sc = a.scratch + (uint64_t)wave * a.scratch_stride;
+    const uint64_t brow_bytes = ((uint64_t)(a.max_len + 66) * 8 + 63) & ~(uint64_t)63;
+    const uint64_t adv_bytes = ((uint64_t)a.max_len + 66 + 63) & ~(uint64_t)63;
+    FastScratch fs;
+    fs.nrows = a.cascade_rows ? a.cascade_rows : 1u;
+    fs.rows = reinterpret_cast<unsigned long long *>(sc);
+    fs.row_elems = (uint32_t)(brow_bytes / 8);
+    fs.advice = sc + (uint64_t)fs.nrows * brow_bytes;
+    fs.zrow = fs.advice + adv_bytes;
+    fs.ckpt = reinterpret_cast<int *>(fs.zrow + a.zrow_bytes);
+    fs.ck_ints = ALN_CK_SLOTS * 18 * 64;
+    return fs;
+}
+
+// ---- cooperative passes (CoopRec, aln_device.h)
+struct CoopCtx {
+    uint32_t *ctl;            // control words; null: off
+    uint32_t *words;          // claim words, one per fill wave
+    uint32_t nw, nw_pad;      // fill waves; claim words incl. padding (a multiple of 64)
+    CoopRec *recs;
+    uint32_t wave;            // this wave = its record
+};
+typedef unsigned long long gran_t;
+__device__ __forceinline__ uint32_t coop_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coop_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ gran_t gran_ld(const gran_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gran_st(gran_t *p, uint32_t v, uint32_t tag) { __hip_atomic_store(p, ((gran_t)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ CoopCtx coop_ctx(const FillArgs &a, uint32_t wave)
+{
+    CoopCtx c;
+    c.ctl = a.coop;
+    c.nw = a.coop_waves; c.nw_pad = (a.coop_waves + 63u) & ~63u;
+    c.words = a.coop ? a.coop + ALN_COOP_CTL_WORDS : nullptr;
+    c.recs = a.coop ? reinterpret_cast<CoopRec *>(c.words + c.nw_pad) : nullptr;
+    c.wave = wave;
+    return c;
+}
+// a strip's end-cell candidate, corner and status as granules of its pass
+__device__ __forceinline__ void coop_put_cand(CoopRec *r, uint32_t s, uint32_t tag, const FastOut &o, int lane)
+{
+    if (lane == 0) {
+        gran_t *c = r->cand[s];
+        gran_st(c, (uint32_t)o.bv, tag | s); gran_st(c + 1, o.by, tag | s); gran_st(c + 2, o.bx, tag | s); gran_st(c + 3, (uint32_t)o.corner, tag | s);
+        gran_st(c + 4, o.aborted ? 1u : 0u, tag | s);
+    }
+}
+// opens this wave's record: the pair's granule, then the claim word -- ns - 1 strips are up for grabs -- then the counters that
+// make other waves look.  announce = false (testing): kind 0, nobody but the owner claims.
+__device__ __forceinline__ void coop_open(const CoopCtx &c, int lane, uint32_t pair, uint32_t tag, uint32_t seq, uint32_t ns, uint32_t R, uint32_t own,
+                                          bool urgent, bool announce)
+{
+    if (lane == 0) {
+        gran_st(&c.recs[c.wave].pairg, pair, tag | 127u);
+        coop_st(c.words + c.wave, aln_coop_word(seq, R, own, announce ? (urgent ? ALN_COOP_KIND_URGENT : ALN_COOP_KIND_LAZY) : 0u, ns, ns - 1u));
+        if (announce) {
+            __hip_atomic_fetch_add(c.ctl + (urgent ? ALN_COOP_UOPEN : ALN_COOP_LOPEN), ns - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (urgent) {
+                const uint32_t i = __hip_atomic_fetch_add(c.ctl + ALN_COOP_ULOGW, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                coop_st(c.ctl + ALN_COOP_ULOG + (i & 15u), c.wave + 1u);
+            }
+        }
+    }
+}
+// The next unclaimed strip of wave w's open pass, or -1; word: the claim word the strip was taken from (wave-uniform).  own: the
+// caller is w itself (it also claims from a pass it did not announce).
+__device__ __forceinline__ int coop_claim(const CoopCtx &c, uint32_t w, int lane, bool own, uint32_t &word)
+{
+    int strip = -1;
+    uint32_t v = 0;
+    if (lane == 0) {
+        uint32_t *p = c.words + w;
+        v = coop_ld(p);
+        for (;;) {
+            const uint32_t left = v & 0x7fu, ns = (v >> 7) & 0x7fu, kind = (v >> 14) & 3u;
+            if (left == 0u || (kind == 0u && !own)) break;
+            if (__hip_atomic_compare_exchange_strong(p, &v, v - 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                strip = (int)(ns - left);
+                if (kind) __hip_atomic_fetch_add(c.ctl + (kind == ALN_COOP_KIND_URGENT ? ALN_COOP_UOPEN : ALN_COOP_LOPEN), 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    strip = __builtin_amdgcn_readfirstlane(strip);
+    word = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return strip;
+}
+// A record with strips to give away, or false.  urgent_only: what a wave between two pairs asks (re-fills only).  Cheap when there
+// is nothing (one 16-byte load of the counters' line); else the log of the last urgent opens, then a scan of the claim words.
+__device__ __forceinline__ bool coop_find(const CoopCtx &c, bool urgent_only, int lane, uint32_t &wave_out, bool &all_done, uint32_t n_pairs)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(c.ctl) : "memory");
+    const uint32_t uopen = q.x, lopen = urgent_only ? 0u : q.y, wi = q.z;
+    all_done = q.w >= n_pairs;
+    // (the counters are exact only in the long run -- a claim takes the word before it takes the counter down -- hence "signed")
+    if ((int32_t)uopen <= 0 && (int32_t)lopen <= 0) return false;
+    const uint32_t kmin = ((int32_t)lopen > 0) ? ALN_COOP_KIND_LAZY : ALN_COOP_KIND_URGENT;
+    if ((int32_t)uopen > 0) {                                // the last urgent opens
+        uint32_t cand = 0, word = 0;
+        if ((uint32_t)lane < 16u && (uint32_t)lane < wi) cand = coop_ld(c.ctl + ALN_COOP_ULOG + ((wi - 1u - (uint32_t)lane) & 15u));
+        if (cand != 0 && cand <= c.nw) word = coop_ld(c.words + cand - 1u);
+        const uint64_t m = __ballot((word & 0x7fu) != 0u && ((word >> 14) & 3u) == ALN_COOP_KIND_URGENT);
+        if (m) { wave_out = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m)) - 1u; return true; }
+    }
+    // scan, four loads of 64 words in flight; every wave starts somewhere else
+    if (lane == 0) __hip_atomic_fetch_add(c.ctl + ALN_COOP_SCANS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t start = ((c.wave * 832u) % c.nw_pad) & ~63u;
+    for (uint32_t i = 0; i < c.nw_pad; i += 256u) {
+        uint32_t v[4], idx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            idx[j] = (start + i + 64u * j + (uint32_t)lane) % c.nw_pad;
+            v[j] = (i + 64u * j < c.nw_pad) ? coop_ld(c.words + idx[j]) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t kind = (v[j] >> 14) & 3u;
+            const uint64_t m = __ballot((v[j] & 0x7fu) != 0u && kind >= kmin && idx[j] != c.wave);
+            if (m) { wave_out = (uint32_t)__builtin_amdgcn_readlane((int)idx[j], (int)__builtin_ctzll(m)); return true; }
+        }
+    }
+    return false;
+}
+
+// Strip s >= 1 of a pass over `pair`: on the wave that owns the pair (open == false: the strips run one after the other and `o`
+// carries the lane candidates along) or on any wave that claimed it (open: `o` starts empty and the strip's candidate goes to the
+// owner's record).  `in` arrives with this wave's constants (lane, S, profile, penalties); everything about the pair is set here.
+// Ru: 0 = skewed layout, else uniform strips of 64 Ru rows; own: strip 0's bottom row keeps row 0 to itself.
+template <int SEM, bool PWM>
+__device__ __forceinline__ void coop_run_strip(FastIn in, const FillArgs &a, uint32_t pair, uint32_t ns, uint32_t Ru, uint32_t own, uint32_t tag,
+                                               uint32_t owner, CoopRec *rec, uint32_t s, FastOut &o, bool open, int del, int ext)
+{
+    const PairDesc &desc = a.descs[pair];
     const uint32_t N = desc.N, M = desc.M;
+    const FastScratch fs = fast_scratch(a, owner);
     in.N = N; in.M = M;
     in.q = a.seqs + desc.q_off;
     in.t = a.seqs + desc.t_off;
@@ -710,43 +886,213 @@ __device__ __forceinline__ bool do_pair_fast(FastIn in, const FastScratch &fs, c
     in.hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
     in.adv_any = false;
     in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0;
-    in.ck_mode = 0; in.last_flip = 0;
+    in.ck_mode = 0; in.last_flip = 0; in.ck_stop = 0;
     in.store_dirs = a.store_dirs != 0;
-    in.wt_dirs = a.doneq != nullptr;
+    in.wt_dirs = a.doneq != nullptr || a.coop != nullptr;
     in.pwm = a.pwm != 0;
     in.pwm_words = a.pwm_words;
-    if (in.hazard)
-        for (uint32_t x = lane; x <= N + 1; x += 64) in.advice[x] = 0;      // the bottom-row record is rewritten by every pass
-    __threadfence_block();
+    in.advice = fs.advice; in.zrow = fs.zrow; in.ckpt = fs.ckpt;
+    // rows: a strip never writes the row it reads.  Strip 0 writes row 0 -- which stays as it is when the pass may be repaired
+    // (own) --, the strips below alternate between two rows (a strip is always behind the one whose row it overwrites: that one
+    // waits, column by column, for the strip in between)
+    const uint32_t r_out = own ? 1u + ((s - 1u) & 1u) : (s & 1u), r_in = s == 1u ? 0u : (own ? 1u + (s & 1u) : ((s - 1u) & 1u));
+    in.brow_in = fs.rows + (size_t)r_in * fs.row_elems;
+    in.brow_out = fs.rows + (size_t)r_out * fs.row_elems;
+    in.strip_rows = Ru ? 64u * Ru : (uint32_t)ALN_STRIP_ROWS;
+    in.strip_q16 = (uint32_t)((Ru ? aln_uniform_strip_bytes(N, Ru) : aln_strip_bytes(N)) / 16u);
+    in.tag_base = tag;
+    const bool last = s + 1u == ns;
+    const int R = Ru ? (int)Ru : (last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R);
+    if (open) { o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0; }
+    o = fast_strip_next<SEM, PWM>(in, o, s, last, R);
+    if (o.aborted && a.coop && in.lane == 0) __hip_atomic_fetch_add(a.coop + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((a.coop_debug & 128u) && a.coop && !last) {        // testing: does the row this strip leaves behind carry its tag in every column?
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t bad = 0;
+        for (uint32_t x = 1 + in.lane; x <= N; x += 64)
+            if ((uint32_t)(gran_ld(in.brow_out + x) >> 32) != (tag | s)) ++bad;
+        if (__any(bad != 0)) {
+            uint32_t first = 0;
+            if (in.lane == 0) first = __hip_atomic_fetch_add(a.coop + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            if (first == 0) {                            // the first strip that finds any: its shape and the columns, in order
+                if (in.lane == 0) { coop_st(a.coop + 15, (s << 4) | (uint32_t)R); coop_st(a.coop + 16, N); coop_st(a.coop + 17, own | (open ? 2u : 0u) | (ns << 8)); }
+                uint32_t slot = 0;
+                for (uint32_t x0 = 1; x0 <= N && slot < 40; x0 += 64) {
+                    const uint32_t x = x0 + in.lane;
+                    const gran_t g = x <= N ? gran_ld(in.brow_out + x) : ((gran_t)(tag | s) << 32);
+                    uint64_t m = __ballot((uint32_t)(g >> 32) != (tag | s));
+                    while (m && slot < 40) {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        if (in.lane == l) { coop_st(a.coop + 128 + slot, x); coop_st(a.coop + 192 + slot, (uint32_t)(g >> 32)); }
+                        ++slot;
+                    }
+                }
+            }
+        }
+    }
+    if (!open) return;
+    if (is_local<SEM>()) reduce_best<SEM>(o);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this strip's directions, row and bottom-row record are out: now say so
+    coop_put_cand(rec, s, tag, o, in.lane);
+}
 
-    const uint32_t ns = aln_num_strips(M);
-    const uint32_t max_passes = a.max_passes ? a.max_passes : 4u;
-    // repairable: strip 0's bottom row stays as the checkpointed pass wrote it (row 0); the strips below pass theirs through
-    // row 1 in place
-    const bool can_repair = in.hazard && !a.no_repair && (ns == 1 || fs.nrows >= 2);
-    auto strip_io = [&](uint32_t s) {
-        const uint32_t ri = (can_repair && s) ? 1u : 0u, rp = (can_repair && s > 1) ? 1u : 0u;
-        in.brow_in = fs.rows + (size_t)rp * fs.row_ints;
-        in.brow_out = fs.rows + (size_t)ri * fs.row_ints;
-        in.ckpt = fs.ckpt;
-    };
-    uint32_t passes = 0;
-    bool converged = false;
+// One pair on the wave that took it from the queue (helper == false), or every strip this wave can claim from wave w's open pass
+// (helper == true: a pair somebody else owns).  ONE function, so that the strips below strip 0 are instantiated at one place
+// whoever runs them.  epoch: this wave's count of multi-strip passes in this launch (the seq of their tags).
+// Returns true when the pair's directions were written with ordinary stores (the strict-order fallback).
+template <int SEM, bool PWM>
+__device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, const CoopCtx &cp, const FillArgs &a, const bool helper, const uint32_t w,
+                                          uint32_t pair, const uint32_t qpos, uint32_t &epoch, int del, int ext)
+{
+    const int lane = in.lane;
+    uint32_t N = 0, M = 0, ns_skew = 0, max_passes = 0;
+    bool can_repair = false;
+    if (!helper) {
+        const PairDesc &desc = a.descs[pair];
+        N = desc.N; M = desc.M;
+        in.N = N; in.M = M;
+        in.q = a.seqs + desc.q_off;
+        in.t = a.seqs + desc.t_off;
+        in.dirw = reinterpret_cast<uint32_t *>(a.dirs + desc.dir_off);
+        in.hazard = (SEM == ALN_CORE_LOCAL) && (del != ext) && N >= 2;
+        in.adv_any = false;
+        in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0;
+        in.ck_mode = 0; in.last_flip = 0; in.ck_stop = 0;
+        in.store_dirs = a.store_dirs != 0;
+        in.wt_dirs = a.doneq != nullptr || a.coop != nullptr;   // (cooperative passes: a re-fill may rewrite, from another XCD, lines this XCD's L2 still holds)
+        in.pwm = a.pwm != 0;
+        in.pwm_words = a.pwm_words;
+        in.advice = fs.advice; in.zrow = fs.zrow; in.ckpt = fs.ckpt;
+        if (in.hazard)
+            for (uint32_t x = lane; x <= N + 1; x += 64) in.advice[x] = 0;      // the bottom-row record is rewritten by every pass
+        __threadfence_block();
+        ns_skew = aln_num_strips(M);
+        max_passes = a.max_passes ? a.max_passes : 4u;
+        // repairable: strip 0's bottom row stays as the checkpointed pass wrote it (row 0); the strips below alternate between rows 1 and 2
+        can_repair = in.hazard && !a.no_repair && (ns_skew == 1 || fs.nrows >= 3);
+    }
+    CoopRec *rec = cp.ctl ? cp.recs + (helper ? w : cp.wave) : nullptr;
+    bool coop_ok = cp.ctl != nullptr;                    // cleared when a cooperative pass had to give up: the rest runs on this wave alone
+    uint32_t passes = 0, Ru = 0, tag = 0, ns = 0, own = 0;
+    bool converged = false, device_error = false, open = helper;
     FastOut o;
-    for (;;) {                                           // full passes
-        o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0;
-        for (uint32_t s = 0; s < ns; ++s) {
-            const bool last = (s + 1 == ns);
-            if (s > 0) __threadfence_block();            // strip s reads the boundary row strip s-1 stored
-            strip_io(s);
-            in.ck_mode = (passes == 0 && can_repair && s == 0) ? 1 : 0;     // strip 0 of the first pass saves its checkpoints
-            o = fast_strip<SEM, PWM>(in, o, s, last, last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R);
+    o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0;
+    for (;;) {                                           // full passes (a helper: once through the strips)
+        if (!helper) {
+            // A re-fill (the pair is late: every other pair of the batch needs one pass) is cut into more, smaller strips than the
+            // first pass, so that up to eight waves can share it
+            Ru = (passes != 0 && coop_ok && SEM == ALN_CORE_LOCAL && !PWM && !(a.coop_debug & 4u)) ? aln_coop_uniform_r(M) : 0u;
+            const uint32_t srows = Ru ? 64u * Ru : (uint32_t)ALN_STRIP_ROWS;
+            ns = (M + srows - 1u) / srows;
+            own = (passes == 0 && can_repair) ? 1u : 0u;
+            // the tag of this pass's granules (rows, bottom-row record, candidates); when the 12 bits of the count wrap, tags of
+            // this launch could come back: the rows are cleared first
+            ++epoch;
+            if ((epoch & 0xfffu) == 0u) {
+                for (uint32_t x = lane; x < fs.nrows * fs.row_elems; x += 64) fs.rows[x] = 0ull;
+                for (uint32_t x = lane; x < a.zrow_bytes / 8u; x += 64) reinterpret_cast<unsigned long long *>(fs.zrow)[x] = 0ull;
+                __threadfence();
+                ++epoch;
+            }
+            tag = aln_coop_tag(a.salt, epoch);
+            // (first passes: only the pairs taken last can still be running when the queue is dry and waves have nothing else to do)
+            open = coop_ok && ns >= 2 && ns <= ALN_COOP_MAX_NS && (passes != 0 || (qpos >= a.coop_tail && !(a.coop_debug & 1u)));
+            if (open) coop_open(cp, lane, pair, tag, epoch, ns, Ru, own, passes != 0, !(a.coop_debug & 2u));
+            o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0;
+            in.brow_in = fs.rows; in.brow_out = fs.rows;
+            in.strip_rows = srows;
+            in.strip_q16 = (uint32_t)((Ru ? aln_uniform_strip_bytes(N, Ru) : aln_strip_bytes(N)) / 16u);
+            in.tag_base = tag;
+            in.ck_mode = (passes == 0 && can_repair) ? 1 : 0;                   // strip 0 of the first pass saves its checkpoints
+            o = fast_strip_first<SEM, PWM>(in, o, ns == 1, Ru ? (int)Ru : (ns == 1 ? aln_pick_r(M) : ALN_FULL_R));
+            in.ck_mode = 0;
+            if (open) {
+                if (is_local<SEM>()) reduce_best<SEM>(o);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                coop_put_cand(rec, 0u, tag, o, lane);
+            }
+        }
+        // ---- the strips below strip 0: in order on this wave (not open), or whichever this wave can claim (the owner of an open pass
+        // and every helper alike)
+        for (uint32_t snext = 1;;) {
+            uint32_t s = snext;
+            if (open) {
+                uint32_t word;
+                const int c = coop_claim(cp, helper ? w : cp.wave, lane, !helper, word);
+                if (c < 0) break;
+                s = (uint32_t)c;
+                if (helper) {
+                    ns = (word >> 7) & 0x7fu; own = (word >> 16) & 1u; Ru = (word >> 17) & 7u; tag = aln_coop_tag(a.salt, word >> 20);
+                    // the pair: a granule of the same pass (written before the claim word; the tag says it is not an older pass's)
+                    gran_t g = gran_ld(&rec->pairg);
+                    for (uint32_t spins = 0; (uint32_t)(g >> 32) != (tag | 127u) && spins < 100000u; ++spins) { __builtin_amdgcn_s_sleep(2); g = gran_ld(&rec->pairg); }
+                    pair = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)g);
+                    if ((uint32_t)(g >> 32) != (tag | 127u) || pair >= a.n_descs || s >= ns || Ru > 4u) {    // cannot be; never index by it
+                        o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.aborted = true;
+                        if (lane == 0) __hip_atomic_fetch_add(cp.ctl + 13, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        coop_put_cand(rec, s, tag, o, lane);
+                        continue;
+                    }
+                    const PairDesc &d = a.descs[pair];
+                    if (((word >> 14) & 3u) == ALN_COOP_KIND_URGENT) __builtin_amdgcn_s_setprio(2);       // a re-fill: the pair is late already
+                    else set_wave_priority((uint64_t)d.N * d.M, a.max_cells);
+                    if (lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_HELPED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (s >= ns) break;
+                ++snext;
+            }
+            coop_run_strip<SEM, PWM>(in, a, pair, ns, Ru, own, tag, helper ? w : cp.wave, rec, s, o, open, del, ext);
+        }
+        if (helper) return false;
+        bool pass_bad = false;
+        if (!open) pass_bad = o.aborted;                 // (a strip of this wave's own pass never waits: cannot be)
+        else {
+            // Every strip has been claimed; the waves that run the others are resident and their own waits are bounded.  Lane s
+            // polls the five granules of strip s; all of them carry the pass's tag once the strip is through.
+            gran_t g[5] = {0, 0, 0, 0, 0};
+            uint32_t spins = 0;
+            for (;;) {
+                bool ok = true;
+                if ((uint32_t)lane < ns) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) { g[i] = gran_ld(rec->cand[lane] + i); ok = ok && (uint32_t)(g[i] >> 32) == (tag | (uint32_t)lane); }
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1u << 18)) { device_error = true; break; }
+            }
+            if (device_error) { if (lane == 0) __hip_atomic_fetch_add(cp.ctl + 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (lane == 0 && spins) __hip_atomic_fetch_add(cp.ctl + 9, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the strips' candidates, merged with the exact tie rule; every lane ends up with the winner
+            o.bv = INT_MIN; o.by = 0; o.bx = 0;
+            if ((uint32_t)lane < ns) { o.bv = (int)(uint32_t)g[0]; o.by = (uint32_t)g[1]; o.bx = (uint32_t)g[2]; }
+            pass_bad = __any((uint32_t)lane < ns && (uint32_t)g[4] != 0u) != 0;
+            if (is_local<SEM>()) reduce_best<SEM>(o);
+            o.corner = __builtin_amdgcn_readlane((int)(uint32_t)g[3], (int)(ns - 1u));
+            o.aborted = false;
+        }
+        uint32_t last_flip = 0;
+        bool zbad = false;
+        if (!pass_bad && in.hazard) {
+            converged = adopt_advice_zdw(in.advice, reinterpret_cast<const unsigned long long *>(in.zrow), tag | (ns - 1u), N, M, Ru, lane, last_flip, zbad);
+            pass_bad = zbad;
+            if (zbad && cp.ctl && lane == 0) __hip_atomic_fetch_add(cp.ctl + 12, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pass_bad) {                                  // a strip gave up waiting (should not happen): this pass again, alone
+            if (!coop_ok) { device_error = true; break; }
+            coop_ok = false;
+            if (lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_ABORTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (in.hazard) for (uint32_t x = lane; x <= N + 1; x += 64) in.advice[x] = 0;     // (adopt may have touched it)
+            __threadfence_block();
+            if (passes != 0) { device_error = true; break; }               // a re-fill's advice cannot be rebuilt here: give the pair up
+            continue;
         }
         ++passes;
         __threadfence_block();
         if (!in.hazard) { converged = true; break; }
-        uint32_t last_flip = 0;
-        converged = adopt_advice_zdw(in.advice, reinterpret_cast<const uint32_t *>(in.zrow), N, M, lane, last_flip);
         if (converged) break;
         if (passes == 1 && can_repair) {
             // Localized repair.  The new advice perturbs strip 0 from column last_flip's step on; strip 0 re-runs its leading
@@ -756,36 +1102,47 @@ __device__ __forceinline__ bool do_pair_fast(FastIn in, const FastScratch &fs, c
             // strip (a cascade through per-strip checkpoints never once re-converged), so that case is re-filled in full.
             uint32_t repairs = 0;
             bool failed = false;
+            in.strip_rows = (uint32_t)ALN_STRIP_ROWS;
+            in.strip_q16 = (uint32_t)(aln_strip_bytes(N) / 16u);
+            in.brow_in = fs.rows; in.brow_out = fs.rows;
             while (!converged && !failed && repairs < 8) {
                 ++repairs;
                 passes += 0x100u;                        // repair rounds are counted in bits 8..15
                 if (last_flip > 512u) { failed = true; passes |= 0x100000u; break; }    // beyond the last checkpoint
                 in.ck_mode = 2;
                 in.last_flip = last_flip;
-                strip_io(0);
                 FastOut ro = o;
                 ro.repaired = false; ro.c_out = 0;
-                ro = fast_strip<SEM, PWM>(in, ro, 0, ns == 1, ns == 1 ? aln_pick_r(M) : ALN_FULL_R);
+                ro = fast_strip_first<SEM, PWM>(in, ro, ns_skew == 1, ns_skew == 1 ? aln_pick_r(M) : ALN_FULL_R);
                 __threadfence_block();
                 if (!__any(ro.repaired)) { failed = true; passes |= 0x300000u; break; }       // no re-convergence (or a stale end-cell candidate)
                 if (ro.c_out != 0) { failed = true; passes |= 0x200000u; break; }            // strip 0's bottom row moved
                 passes = (passes & ~0xf0000u) | ((ro.ck_slot + 1u) << 16);               // diagnostics: where the repair re-converged
                 o = ro;
-                if (ns > 1) { converged = true; break; }                                  // the bottom strip, hence z, is untouched
-                converged = adopt_advice_zdw(in.advice, reinterpret_cast<const uint32_t *>(in.zrow), N, M, lane, last_flip);   // single strip: z may have moved
+                if (ns_skew > 1) { converged = true; break; }                             // the bottom strip, hence z, is untouched
+                // single strip: z may have moved (the repair run rewrote the record with this pass's tag)
+                converged = adopt_advice_zdw(in.advice, reinterpret_cast<const unsigned long long *>(in.zrow), tag, N, M, 0u, lane, last_flip, zbad);
+                if (zbad) { failed = true; break; }
             }
+            in.ck_mode = 0; in.last_flip = 0;
             if (converged) break;
             if (!(passes & 0xf00000u)) passes |= 0x400000u;
         }
         if ((passes & 0xffu) >= max_passes) break;
     }
+    PairDesc &desc = a.descs[pair];
+    aln_pair_result &res = a.results[pair];
+    if (device_error) {                                  // a strip handed to another wave never reported: nothing here may be trusted
+        if (lane == 0) { skip_invalid(res, ALN_ERR_DEVICE, 0); desc.layout = ALN_LAYOUT_SKEW; }
+        return true;
+    }
     if (!converged) {                                    // strict reference order (exact for every input)
         Wave<int> c;
         c.lane = 0; c.N = N; c.M = M; c.q = in.q; c.t = in.t; c.S = in.S; c.cols = in.cols; c.del = del; c.ext = ext;
-        c.dirw = in.dirw; c.brow = fs.rows; c.hmat = nullptr; c.store_dirs = in.store_dirs; c.pwm = in.pwm;
+        c.dirw = in.dirw; c.brow = reinterpret_cast<int *>(fs.rows); c.hmat = nullptr; c.store_dirs = in.store_dirs; c.pwm = in.pwm;
         c.bv = 0; c.by = 0; c.bx = 0; c.corner = 0;
         if (lane == 0) serial_fill_impl<int, SEM>(c);
-        __threadfence_block();
+        __threadfence();                                 // (ordinary stores, also into the rows other waves' granules land in later: none stays dirty here)
         if (lane == 0) {
             desc.layout = ALN_LAYOUT_ROWMAJOR;
             write_result<SEM>(res, (double)c.bv, c.by, c.bx, (double)c.corner, N, M, passes | 0x80u, 1u, in.pwm);
@@ -794,7 +1151,7 @@ __device__ __forceinline__ bool do_pair_fast(FastIn in, const FastScratch &fs, c
     }
     if (is_local<SEM>()) reduce_best<SEM>(o);
     if (lane == 0) {
-        desc.layout = ALN_LAYOUT_SKEW;
+        desc.layout = Ru ? (ALN_LAYOUT_UBATCH | (Ru << 8)) : ALN_LAYOUT_SKEW;
         write_result<SEM>(res, (double)(o.bv >> 2), o.by, o.bx, (double)(o.corner >> 2), N, M, passes, 1u, in.pwm);
     }
     return false;
@@ -849,27 +1206,6 @@ __device__ __forceinline__ bool pair_codes_ok(const uint8_t *seqs, const PairDes
     for (uint32_t i = (uint32_t)lane; i < d.M; i += 64u) worst_t = max(worst_t, (uint32_t)t[i]);
     return !__any(worst_q >= cols || worst_t >= rows);
 }
-__device__ __forceinline__ void skip_invalid(aln_pair_result &res, int status, int lane)
-{
-    if (lane == 0) {
-        res.f = 0.0; res.score = 0.0; res.end_y = res.end_x = res.start_y = res.start_x = 0;
-        res.aln_len = 0; res.status = status == ALN_PRE_EMPTY_OK ? ALN_OK : status; res.passes = 0; res.flags = 0;
-    }
-}
-
-// The SIMD's instruction arbiter is not fair: among waves of equal priority the oldest wave issues first, and with three
-// VALU-bound waves per SIMD the youngest gets ~13 % of the issue slots (measured: 1.5 / 0.9 / 0.35 GCUPS for the three).
-// Throughput does not care, the tail of a small batch does: a large pair taken at t = 0 by a youngest wave was still in its
-// first pass when everything else had finished.  So the wave's priority follows the size of its pair (thirds of the
-// queue's largest pair): in the LPT order this is "oldest pair first" -- a large pair is never starved by the smaller pairs
-// the older waves of its SIMD move on to.
-__device__ __forceinline__ void set_wave_priority(uint64_t cells, uint64_t max_cells)
-{
-    if (3 * cells > 2 * max_cells) __builtin_amdgcn_s_setprio(2);          // 3 belongs to the walk kernel that runs beside the fill
-    else if (3 * cells > max_cells) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 template <typename SC, int SEM>
 __global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
 {
@@ -920,19 +1256,11 @@ void aln_fill_fast_kernel(FillArgs a)
     FastIn in;
     in.lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    uint8_t *sc = a.scratch + (uint64_t)wave * a.scratch_stride;
-    const uint64_t brow_bytes = ((uint64_t)(a.max_len + 66) * 4 + 63) & ~(uint64_t)63;
-    const uint64_t adv_bytes = ((uint64_t)a.max_len + 66 + 63) & ~(uint64_t)63;
-    // [boundary rows][advice][bottom-row record][checkpoint sets]
-    FastScratch fs;
-    fs.nrows = a.cascade_rows ? a.cascade_rows : 1u;
-    fs.rows = reinterpret_cast<int *>(sc);
-    fs.row_ints = (uint32_t)(brow_bytes / 4);
+    const FastScratch fs = fast_scratch(a, wave);
+    const CoopCtx cp = coop_ctx(a, wave);
     in.brow_in = fs.rows; in.brow_out = fs.rows;
-    in.advice = sc + (uint64_t)fs.nrows * brow_bytes;
-    in.zrow = in.advice + adv_bytes;
-    fs.ckpt = reinterpret_cast<int *>(in.zrow + a.zrow_bytes);
-    fs.ck_ints = ALN_CK_SLOTS * 18 * 64;
+    in.advice = fs.advice;
+    in.zrow = fs.zrow;
     in.ckpt = fs.ckpt;
     in.S = S;
     in.cols = a.cols;
@@ -941,24 +1269,56 @@ void aln_fill_fast_kernel(FillArgs a)
     in.ne4 = -4 * (int)a.ext;
     in.gin = nullptr; in.gout = nullptr; in.abort_flag = nullptr; in.qo_pad = nullptr; in.bring = nullptr;
     in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.adv_any = false; in.store_dirs = true; in.pwm = false; in.pwm_words = nullptr; in.ck_mode = 0; in.last_flip = 0;
-    uint32_t pair, qpos;
-    while (next_pair(a, in.lane, pair, qpos)) {
-        PairDesc &desc = a.descs[pair];
-        aln_pair_result &res = a.results[pair];
-        bool plain = false;
-        if (desc.status != ALN_OK) skip_invalid(res, desc.status, in.lane);
-        else if (!pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, in.lane)) skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, in.lane);
-        else {
+    in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0; in.ck_stop = 0; in.wt_dirs = false;
+    in.strip_rows = ALN_STRIP_ROWS; in.strip_q16 = 0; in.tag_base = 0;
+    uint32_t pair = 0, qpos = 0, epoch = 0;
+    bool dry = false;
+    uint64_t idle_since = 0;
+    for (;;) {
+        // what next: strips other waves give away -- re-fills (urgent) before the next pair, first passes too once the queue is dry --
+        // else the next pair of the queue, else (the queue is dry) wait for either
+        bool all_done = false, helper = false;
+        uint32_t w = 0;
+        if (cp.ctl) helper = coop_find(cp, !dry, in.lane, w, all_done, a.n_pairs);
+        if (!helper) {
+            if (!dry && !next_pair(a, in.lane, pair, qpos)) {
+                dry = true;
+                if (cp.ctl) continue;                    // first passes of other waves' pairs next
+            }
+            if (dry) {
+                // nobody has a strip to give away right now: stay while pairs are still being filled -- any of them may yet need a
+                // second pass -- but look rarely (a few thousand idle waves polling one line every few microseconds slowed the
+                // waves that still work by 20 %)
+                if (!cp.ctl || !a.coop_linger || all_done) break;
+                if (idle_since == 0) idle_since = wall_clock64();
+                else if (wall_clock64() - idle_since > 200000000ull) break;        // 2 s of nothing: leave
+                __builtin_amdgcn_s_setprio(0);
+                for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);         // ~25 us
+                continue;
+            }
+            PairDesc &desc = a.descs[pair];
+            aln_pair_result &res = a.results[pair];
+            const bool bad_shape = desc.status != ALN_OK;
+            if (bad_shape || !pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, in.lane)) {
+                skip_invalid(res, bad_shape ? desc.status : ALN_ERR_CODE_OUT_OF_RANGE, in.lane);
+                pair_done(a, in.lane, pair, false);
+                if (cp.ctl && in.lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_FINISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
             set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
-#ifdef ALN_STAMPS                                        // tools/tail_timeline.py: when did which wave work on this pair (score-only runs)
-            const uint64_t ts = wall_clock64();
-#endif
-            plain = do_pair_fast<SEM, PWM>(in, fs, a, desc, res, (int)a.del, (int)a.ext);
-#ifdef ALN_STAMPS
-            if (in.lane == 0) { res.aln_len = (uint32_t)ts; res.start_x = (uint32_t)wall_clock64(); res.start_y = wave; }
-#endif
         }
+        idle_since = 0;
+#ifdef ALN_STAMPS                                        // tools/tail_timeline.py: when did which wave work on this pair (score-only runs)
+        const uint64_t ts = wall_clock64();
+#endif
+        // (one call for both: the strips below strip 0 are the same code whoever runs them)
+        const bool plain = fast_work<SEM, PWM>(in, fs, cp, a, helper, w, pair, qpos, epoch, (int)a.del, (int)a.ext);
+        if (helper) continue;
+#ifdef ALN_STAMPS
+        if (in.lane == 0) { aln_pair_result &res = a.results[pair]; res.aln_len = (uint32_t)ts; res.start_x = (uint32_t)wall_clock64(); res.start_y = wave; }
+#endif
         pair_done(a, in.lane, pair, plain);
+        if (cp.ctl && in.lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_FINISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1332,6 +1692,7 @@ __global__ __launch_bounds__(64) void aln_single_serial_kernel(SingleArgs a)
 
 // arms pass 0 and clears the advice / bottom-row bytes.  A pair the validation kernel rejected (a residue code outside the
 // matrix) is not armed: every later kernel of the route returns at once, and the summary carries the status.
+#if ALN_TU & ALN_PART_SINGLE
 extern "C" __global__ void aln_single_init_kernel(SingleArgs a, uint32_t n_bytes)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1341,6 +1702,9 @@ extern "C" __global__ void aln_single_init_kernel(SingleArgs a, uint32_t n_bytes
     if (i == 0 && st != ALN_OK) skip_invalid(a.results[a.pair], st, 0);
 }
 
+#endif
+
+#if ALN_TU & ALN_PART_GENERIC
 // ---------------------------------------------------------------- residue-code validation
 // The reference indexes the matrix with every residue (simple/mod.rs:85,198) and panics on a code outside it; here one wave
 // per pair scans both sequences and turns that into the pair's status (ALN_ERR_CODE_OUT_OF_RANGE).  The batch fill kernels do
@@ -1361,6 +1725,9 @@ extern "C" __global__ __launch_bounds__(256) void aln_validate_kernel(const uint
     if (__any(bad != 0) && lane == 0) d.status = ALN_ERR_CODE_OUT_OF_RANGE;
 }
 
+#endif
+
+#if ALN_TU & ALN_PART_TB
 // ---------------------------------------------------------------- traceback
 // Direction of cell (y, x) from the packed store (borders are implicit: simple/mod.rs:55-67).
 __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bool global, uint32_t y, uint32_t x)
@@ -1377,7 +1744,7 @@ __device__ __forceinline__ int dir_at(const uint8_t *dirs, const PairDesc &d, bo
     uint32_t strip, i;
     int R;
     uint64_t strip_bytes;
-    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) {
+    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM || (d.layout & 0xffu) == ALN_LAYOUT_UBATCH) {
         R = (int)((d.layout >> 8) & 0xffu);
         strip = (y - 1) / (64u * R);
         i = (y - 1) - strip * 64u * R;
@@ -1408,7 +1775,7 @@ __device__ __forceinline__ StripView strip_view(const uint8_t *dirs, const PairD
 {
     StripView v;
     const uint8_t *base = dirs + d.dir_off;
-    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM) {
+    if ((d.layout & 0xffu) == ALN_LAYOUT_UNIFORM || (d.layout & 0xffu) == ALN_LAYOUT_UBATCH) {
         v.R = (d.layout >> 8) & 0xffu;
         const uint32_t strip = (y - 1) / (64u * v.R);
         v.y0 = strip * 64u * v.R;
@@ -1901,22 +2268,37 @@ extern "C" __global__ void aln_unpack_directions_kernel(const uint8_t *dirs, con
     }
 }
 
+#endif   // ALN_PART_TB
+
 // ---------------------------------------------------------------- launch helpers used by aln_host.hip
+#if ALN_TU & ALN_PART_FAST_CL
+extern "C" void aln_launch_fill_fast_cl(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, false>), dim3(grid), dim3(256), lds_bytes, s, *a);
+}
+#endif
+#if ALN_TU & ALN_PART_FAST_REST
+extern "C" void aln_launch_fill_fast_rest(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
+{
+    const dim3 g(grid), b(256);
+    switch (a->semantics) {
+    case ALN_CORE_GLOBAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_GLOBAL, false>), g, b, lds_bytes, s, *a); break;
+    case ALN_CORE_LOCAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, true>), g, b, lds_bytes, s, *a); break;   // PWM scoring
+    case ALN_LEGACY_GLOBAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_LEGACY_GLOBAL, false>), g, b, lds_bytes, s, *a); break;
+    default: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_LEGACY_LOCAL, false>), g, b, lds_bytes, s, *a); break;
+    }
+}
+#endif
+#if ALN_TU & ALN_PART_GENERIC
+extern "C" void aln_launch_fill_fast_cl(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
+extern "C" void aln_launch_fill_fast_rest(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), b(256);
 #define ALN_LAUNCH(SC, SEM) hipLaunchKernelGGL((aln_fill_kernel<SC, SEM>), g, b, lds_bytes, s, *a)
-#define ALN_LAUNCH_FAST(SEM) hipLaunchKernelGGL((aln_fill_fast_kernel<SEM, false>), g, b, lds_bytes, s, *a)
     if (is_int && fast) {
-        switch (a->semantics) {
-        case ALN_CORE_GLOBAL: ALN_LAUNCH_FAST(ALN_CORE_GLOBAL); break;
-        case ALN_CORE_LOCAL:
-            if (a->pwm) hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, true>), g, b, lds_bytes, s, *a);
-            else ALN_LAUNCH_FAST(ALN_CORE_LOCAL);
-            break;
-        case ALN_LEGACY_GLOBAL: ALN_LAUNCH_FAST(ALN_LEGACY_GLOBAL); break;
-        default: ALN_LAUNCH_FAST(ALN_LEGACY_LOCAL); break;
-        }
+        if (a->semantics == ALN_CORE_LOCAL && !a->pwm) aln_launch_fill_fast_cl(a, grid, lds_bytes, s);
+        else aln_launch_fill_fast_rest(a, grid, lds_bytes, s);
     } else if (is_int) {
         switch (a->semantics) {
         case ALN_CORE_GLOBAL: ALN_LAUNCH(int, ALN_CORE_GLOBAL); break;
@@ -1928,9 +2310,10 @@ extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_
         if (a->semantics == ALN_CORE_GLOBAL) ALN_LAUNCH(double, ALN_CORE_GLOBAL);
         else ALN_LAUNCH(double, ALN_CORE_LOCAL);
     }
-#undef ALN_LAUNCH_FAST
 #undef ALN_LAUNCH
 }
+#endif
+#if ALN_TU & ALN_PART_SINGLE
 // LDS bytes of the fill kernel for W waves per workgroup (rings + S + query offsets + per-wave profile and boundary ring)
 extern "C" uint32_t aln_single_lds_bytes(uint32_t rows, uint32_t cols, uint32_t R, uint32_t N, uint32_t W)
 {
@@ -1988,6 +2371,8 @@ extern "C" void aln_launch_single(const SingleArgs *a, uint32_t N, int with_seri
 #undef ALN_SINGLE
 #undef ALN_SINGLE_LAUNCH
 }
+#endif
+#if ALN_TU & ALN_PART_GENERIC
 template <typename SC, int SEM>
 static void launch_wgpipe_r(const WgArgs *a, uint32_t lds, hipStream_t s)
 {
@@ -2016,6 +2401,8 @@ extern "C" void aln_launch_validate(const uint8_t *seqs, PairDesc *descs, uint32
 {
     if (n_pairs) hipLaunchKernelGGL(aln_validate_kernel, dim3((n_pairs + 3) / 4), dim3(256), 0, s, seqs, descs, n_pairs, rows, cols, pwm ? 1u : 0u);
 }
+#endif
+#if ALN_TU & ALN_PART_SINGLE
 // the repair run + its finalize (both exit at once unless pass 0's finalize armed ctrl[8]); core local only
 extern "C" void aln_launch_single_repair(const SingleArgs *a0, uint32_t N, hipStream_t s)
 {
@@ -2044,6 +2431,8 @@ extern "C" void aln_launch_single_init(const SingleArgs *a, uint32_t n_bytes, hi
 {
     hipLaunchKernelGGL(aln_single_init_kernel, dim3((n_bytes + 255) / 256), dim3(256), 0, s, *a, n_bytes);
 }
+#endif
+#if ALN_TU & ALN_PART_TB
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
 {
     const uint32_t grid = (a->n_pairs + 63) / 64;
@@ -2077,3 +2466,4 @@ extern "C" void aln_launch_unpack(const uint8_t *dirs, const PairDesc *descs, ui
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(aln_unpack_directions_kernel, dim3(grid), dim3(256), 0, s, dirs, descs, pair, semantics, out);
 }
+#endif

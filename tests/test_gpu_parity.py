@@ -88,6 +88,46 @@ def test_cli_plumbing_book_example(blosum62):
     assert l.alignment.f == 27.0 and l.alignment.coords == ((5, 11), (1, 8))
 
 
+@pytest.mark.parametrize("sem", [_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL, _ffi.LEGACY_LOCAL])
+def test_c_harness_through_the_header(orc, blosum62, tmp_path, sem):
+    """include/aligner_hip.h compiled as C (tests/abi_harness.c): the book example through aln_align_pair with every output, and
+    (q, t), (t, q), (q, q) through aln_align_batch, printed by the C program and compared with the oracle here."""
+    import subprocess
+    from aligner_amd import build as native_build
+    exe = native_build.build_harness()
+    q, t = P("HEAGAWGHEE"), P("PAWHEAE")
+    dele, ext = (8, 8) if sem == _ffi.LEGACY_LOCAL else (11, 2)
+    case = tmp_path / "case.txt"
+    case.write_text("%d %g %g 24 24\n%s\n%d %s\n%d %s\n" % (sem, dele, ext, " ".join("%g" % v for v in blosum62.ravel()),
+                                                         len(q), " ".join(map(str, q.tolist())), len(t), " ".join(map(str, t.tolist()))))
+    out = subprocess.run([exe, str(case)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    facts = {}
+    for line in out.stdout.splitlines():
+        k, _, v = line.partition(" ")
+        facts[k] = v.split()
+
+    def summary(words):
+        d = dict(zip(words[0::2], words[1::2])) if words[4] != "end" else None
+        return d
+    def check(prefix, qq, tt, full):
+        ref = orc.align(sem, qq, tt, dele, ext, blosum62, want_matrices=full)
+        w = facts[prefix]
+        assert w[0] == "status" and int(w[1]) == ref["status"]
+        assert float(w[3]) == ref["f"] and float(w[5]) == ref["score"]
+        assert (int(w[7]), int(w[8])) == ref["end"] and (int(w[10]), int(w[11])) == ref["start"]
+        assert [int(v) for v in facts[prefix + "_q_aln"]] == ref["qa"].tolist()
+        assert [int(v) for v in facts[prefix + "_t_aln"]] == ref["ta"].tolist()
+        assert int(w[13]) == len(ref["qa"])
+        if full:
+            assert [int(v) for v in facts[prefix + "_dirs"]] == ref["D"].ravel().tolist()
+            assert [float(v) for v in facts[prefix + "_h"]] == ref["H"].ravel().astype(float).tolist()
+    check("pair", q, t, True)
+    check("batch0", q, t, False)
+    check("batch1", t, q, False)
+    check("batch2", q, q, False)
+
+
 # ---------------------------------------------------------------- differential tests vs the oracle
 @pytest.mark.parametrize("sem", SEMS)
 @pytest.mark.parametrize("shape", [(1, 1), (1, 7), (9, 1), (10, 7), (64, 64), (65, 63), (130, 129), (257, 70),

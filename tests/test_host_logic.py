@@ -119,6 +119,19 @@ def test_native_library_loads_and_exports_every_declared_symbol():
     assert lib.aln_abi_version() == 2
 
 
+def test_header_compiles_as_c99_and_links():
+    """tests/abi_harness.c = include/aligner_hip.h used from C: built with -std=c99 -Wall -Werror (record sizes and offsets are pinned at
+    compile time there), linked against the library; without a case file it only loads the library and compares ABI versions."""
+    import subprocess
+    from aligner_amd import build as native_build
+    native_build.build()
+    exe = native_build.build_harness()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_version_header 2 sizeof_result 48 sizeof_params %d" % C.sizeof(_ffi.Params) in out.stdout
+    assert "abi_version_library 2" in out.stdout
+
+
 def test_no_gpu_means_loud_failure_not_fallback(blosum62):
     """Without a device the product path must raise; it must never produce an answer some other way."""
     import torch
