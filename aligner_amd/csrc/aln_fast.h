@@ -312,7 +312,8 @@ struct FastStrip {
             if constexpr (PWM) pw = pwm_select((uint32_t)qoff); else pw = *reinterpret_cast<const PW *>(prow + qoff);
         }
         // end-cell tie-break term of this step: earlier steps win (core) / later steps win (legacy)
-        const uint32_t kc = SINGLE ? (k & 2047u) : k - chunk0;             // step within the tracker's chunk
+        static_assert(CHUNK == 2048u, "the tracker's chunks start at multiples of 2048 steps");
+        const uint32_t kc = k & 2047u;                                      // step within the tracker's chunk (scalar arithmetic: k is uniform)
         const int kterm = (SEM == ALN_CORE_LOCAL) ? (int)(2047u - kc) : (int)kc;
         const uint32_t xm1 = k - (uint32_t)lane;
         if (!MASKED || xm1 < N) {
@@ -596,9 +597,10 @@ struct FastStrip {
         uint4 v = make_uint4(0, 0, 0, 0);
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; ++j) {
-            // wave-uniform by construction; say so (in strip 0 of a hazard pair the compiler otherwise carries the step
-            // counter in a VGPR and pays for it in every step)
-            const uint32_t k0 = FIRST ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((kb + j) * SPB)) : (kb + j) * SPB;
+            // wave-uniform by construction; say so (in strip 0 of a hazard pair, and wherever the strip's shape comes out of
+            // a vector load -- the batch kernels -- the compiler otherwise carries the step counter in a VGPR and pays for
+            // it in every step: four VALU instructions per step, measured as 5 % of the C5 fill)
+            const uint32_t k0 = (FIRST || !SINGLE) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((kb + j) * SPB)) : (kb + j) * SPB;
             if (SINGLE && !FIRST && ((k0 + SPB) & 15u) == 0) stage_boundary16((k0 + SPB) >> 4);   // one block ahead
 #pragma unroll
             for (int kk = 0; kk < SPB; ++kk) step<MASKED>(k0 + kk);
@@ -837,7 +839,7 @@ struct FastStrip {
             if (kb * SPB == chunk_base + CHUNK) {         // every semantics advances the chunk; only the local ones track an end cell
                 if (LOCAL) fold(o, chunk_base);
                 chunk_base += CHUNK;
-                chunk0 = chunk_base;
+                chunk0 = uniform32(chunk_base);              // (an SGPR: the tracker term of every cell is built from it)
             }
         }
         if (SINGLE && !LAST && !(ASMPATH && !FIRST)) publish(nkb * SPB - 1);     // the last (up to 15) columns (the asm publishes after every unit)

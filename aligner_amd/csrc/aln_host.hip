@@ -378,7 +378,7 @@ struct Chunk {
     size_t counter_bytes = 256;
     bool overlap = false;             // walk waves beside the fill (in-kernel overlapped traceback)
     // cooperative passes of the fast batch kernel (CoopRec, aln_device.h): hint ring capacities, bytes of the control block
-    bool coop = false;
+    bool coop = false, coop_linger = false;
     uint32_t coop_tail = 0;
     uint64_t coop_bytes = 0;
     // sequences: either one contiguous span of the caller's buffer, or gathered pair by pair into pinned staging
@@ -515,7 +515,22 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
     k.cells = cells; k.max_len = max_len;
     k.dir_bytes = dir_total; k.tb_bytes = tb_total; k.tag_bytes = tag_total; k.hmat_elems = hm_total;
 
-    // ---- LPT order: largest pairs first into the device work queue
+    // ---- LPT order: longest pairs first into the device work queue.  "Longest" = the time one wave needs, not the cells: a strip of
+    // R rows per lane takes N + lanes - 1 steps of about 12 + 10.5 R instructions, so a 1900 x 270 pair (one strip of 5 rows per
+    // lane) keeps its wave as long as a 1000 x 1000 pair with twice the cells -- ordered by cells it was taken when the queue was
+    // almost dry and ended the 8-way shard's fill 0.9 ms after everybody else (tools/tail_timeline.py).
+    auto pair_cost = [](const PairDesc &d) -> uint64_t {
+        if (d.status != ALN_OK) return 0;
+        uint64_t cost = 0;
+        const uint32_t ns = aln_num_strips(d.M);
+        for (uint32_t st = 0; st < ns; ++st) {
+            const uint32_t rows = std::min<uint32_t>(d.M - st * ALN_STRIP_ROWS, ALN_STRIP_ROWS);
+            const uint32_t R = st + 1 == ns ? (uint32_t)aln_pick_r(rows) : (uint32_t)ALN_FULL_R, L = (rows + R - 1) / R;
+            cost += (uint64_t)(d.N + L - 1) * (24u + 21u * R);
+            if (cost >= (1ull << 40)) return (1ull << 40) - 1;
+        }
+        return cost;
+    };
     k.order.clear();
     k.order.reserve(n);
     {
@@ -530,21 +545,18 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         std::vector<uint64_t> key(k.n_small);
         bool packable = n < (1u << 24);
         for (size_t j = 0; j < k.n_small && packable; ++j) {
-            const PairDesc &d = k.descs[k.order[j]];
-            const uint64_t pc = d.status == ALN_OK ? (uint64_t)d.N * d.M : 0;
-            if (pc >= (1ull << 40)) { packable = false; break; }
+            const uint64_t pc = pair_cost(k.descs[k.order[j]]);
             key[j] = ((~pc & ((1ull << 40) - 1)) << 24) | k.order[j];
         }
         if (packable) {
             std::sort(key.begin(), key.end());
             for (size_t j = 0; j < k.n_small; ++j) k.order[j] = (uint32_t)(key[j] & 0xffffffu);
         } else {
-            std::stable_sort(k.order.begin(), k.order.end(), [&](uint32_t a, uint32_t b) {
-                return (uint64_t)k.descs[a].N * k.descs[a].M > (uint64_t)k.descs[b].N * k.descs[b].M;
-            });
+            std::stable_sort(k.order.begin(), k.order.end(), [&](uint32_t a, uint32_t b) { return pair_cost(k.descs[a]) > pair_cost(k.descs[b]); });
         }
     }
-    k.max_cells = k.order.empty() ? 0 : (uint64_t)k.descs[k.order[0]].N * k.descs[k.order[0]].M;
+    k.max_cells = 0;
+    for (uint32_t i : k.order) if (k.descs[i].status == ALN_OK) k.max_cells = std::max(k.max_cells, (uint64_t)k.descs[i].N * k.descs[i].M);
 
     // ---- grid: persistent waves, 4 per workgroup
     const uint32_t wg_needed = (uint32_t)((k.n_small + 3) / 4);
@@ -576,12 +588,20 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         uint64_t strips = 0;
         for (size_t j = 0; j < k.n_small; ++j) { const PairDesc &d = k.descs[k.order[j]]; if (d.status == ALN_OK) strips += aln_num_strips(d.M); }
         const uint32_t resident = (uint32_t)ctx->cus * 3u;
-        if (!k.overlap) k.grid = std::max(k.grid, (uint32_t)std::min<uint64_t>(resident, (strips + 3) / 4));
-        // first passes give strips away only for the last pairs of the queue: two per resident wave (the pairs that can still be
-        // running when the queue is dry); ALN_COOP_TAIL overrides (pairs from the end)
-        uint64_t tail = 2ull * resident * 4u;
+        // (allow_overlap == false: a chunk of a pipelined call -- the chunks before and after it share the chip with this one, so its
+        // grid stays at one wave per pair, nobody lingers, and only re-fills are shared)
+        const bool alone = allow_overlap;
+        if (!k.overlap && alone) k.grid = std::max(k.grid, (uint32_t)std::min<uint64_t>(resident, (strips + 3) / 4));
+        // First passes give strips away only in batches of fewer than two pairs per resident wave -- there the pairs that are still
+        // running when the queue is dry are large, and idle waves are what fills the chip.  In a larger batch the last pairs are the
+        // shortest ones (measured on the 12 500-pair shard of C5: opening the first passes of its last 6000 pairs cost 0.15 ms of 6.8
+        // and shortened nothing); re-fills are always shared.  ALN_COOP_TAIL overrides (pairs from the end whose first pass is opened).
+        uint64_t tail = (alone && k.n_small < 2ull * resident * 4u) ? k.n_small : 0;
         if (const char *e = getenv("ALN_COOP_TAIL")) tail = strtoull(e, nullptr, 10);
         k.coop_tail = (uint32_t)(k.n_small > tail ? k.n_small - tail : 0);
+        // waves that find the queue dry stay around for strips only when they are what fills the chip: a batch with fewer pairs than
+        // resident waves (measured on the 12 500-pair shard: staying costs the waves that still work 0.2 ms of 7)
+        k.coop_linger = alone && k.n_small < (uint64_t)resident * 4u;
     }
     if (const char *e = getenv("ALN_FILL_WGS")) k.grid = std::max(1u, std::min(k.grid, (uint32_t)atoi(e)));   // experiments: fewer resident fill waves
     if (k.coop) k.coop_bytes = 4ull * (ALN_COOP_CTL_WORDS + (((uint64_t)k.grid * 4 + 63) & ~63ull)) + (uint64_t)k.grid * 4 * sizeof(CoopRec);
@@ -761,7 +781,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     fa.hmat = c.want_h ? s.hmat.p : nullptr; fa.blank = c.p.blank_code;
     fa.n_descs = (uint32_t)k.n;
     fa.coop = k.coop ? s.coop.as<uint32_t>() : nullptr; fa.coop_waves = k.grid * 4u; fa.coop_tail = k.coop_tail; fa.salt = s.salt;
-    { const char *e = getenv("ALN_COOP_LINGER"); fa.coop_linger = e ? (uint32_t)atoi(e) : 1u; }
+    { const char *e = getenv("ALN_COOP_LINGER"); fa.coop_linger = e ? (uint32_t)atoi(e) : (k.coop_linger ? 1u : 0u); }
     { const char *e = getenv("ALN_COOP_DEBUG"); fa.coop_debug = e ? (uint32_t)atoi(e) : 0u; }
     if (fill_after) HIPCHK(hipStreamWaitEvent(st, fill_after, 0));
     if (ev) HIPCHK(hipEventRecord(ev[0], st));

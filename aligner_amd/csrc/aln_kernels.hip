@@ -983,7 +983,12 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
         if (!helper) {
             // A re-fill (the pair is late: every other pair of the batch needs one pass) is cut into more, smaller strips than the
             // first pass, so that up to eight waves can share it
-            Ru = (passes != 0 && coop_ok && SEM == ALN_CORE_LOCAL && !PWM && !(a.coop_debug & 4u)) ? aln_coop_uniform_r(M) : 0u;
+            // -- when that matters: while the queue still holds two pairs or more for every wave, the wave just fills it again by
+            // itself (a shared re-fill takes other waves off their pairs and its smaller strips cost more instructions per cell:
+            // 2 % of the C5 batch's fill when every re-fill was shared).  First passes: see FillArgs::coop_tail.
+            const bool share = coop_ok && (passes != 0 ? (coop_ld(a.counter) + 2u * cp.nw >= a.n_pairs || (a.coop_debug & 8u))
+                                                       : (qpos >= a.coop_tail && !(a.coop_debug & 1u)));
+            Ru = (passes != 0 && share && SEM == ALN_CORE_LOCAL && !PWM && !(a.coop_debug & 4u)) ? aln_coop_uniform_r(M) : 0u;
             const uint32_t srows = Ru ? 64u * Ru : (uint32_t)ALN_STRIP_ROWS;
             ns = (M + srows - 1u) / srows;
             own = (passes == 0 && can_repair) ? 1u : 0u;
@@ -997,8 +1002,7 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
                 ++epoch;
             }
             tag = aln_coop_tag(a.salt, epoch);
-            // (first passes: only the pairs taken last can still be running when the queue is dry and waves have nothing else to do)
-            open = coop_ok && ns >= 2 && ns <= ALN_COOP_MAX_NS && (passes != 0 || (qpos >= a.coop_tail && !(a.coop_debug & 1u)));
+            open = share && ns >= 2 && ns <= ALN_COOP_MAX_NS;
             if (open) coop_open(cp, lane, pair, tag, epoch, ns, Ru, own, passes != 0, !(a.coop_debug & 2u));
             o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0;
             in.brow_in = fs.rows; in.brow_out = fs.rows;

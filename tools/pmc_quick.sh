@@ -1,14 +1,14 @@
 #!/bin/bash
-# quick PMC pass on the fill kernel: usage pmc.sh <tag>
+# quick PMC pass on the fill kernel: usage tools/pmc_quick.sh <tag> [pairs]   (counters in separate rocprofv3 runs, no trace domains)
 set -o pipefail
 TAG=$1
-OUT=gpurun_out/r02/pmc_$TAG
+PAIRS=${2:-100000}
+OUT=gpurun_out/r03/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--pairs 20000 --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-small-configs --no-end-to-end"
+ARGS="--pairs $PAIRS --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-small-configs --no-end-to-end"
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" \
-           "SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_LEVEL_VMEM SQ_INSTS_LDS" \
-           "SQ_INST_CYCLES_VMEM_WR SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"; do
+           "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
   NAME=$(echo $SET | cut -d' ' -f1)
   rocprofv3 --pmc $SET --output-format csv -d $OUT/$NAME -- python3 bench.py $ARGS > $OUT/log_$NAME.txt 2>&1 || { echo "pmc $NAME failed"; tail -3 $OUT/log_$NAME.txt; }
 done
