@@ -63,11 +63,10 @@ static thread_local std::string g_err;
 
 // HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A pipelined batch call keeps
 // four streams busy at once; when other streams of the process (a framework's, a staged batch's) are mapped onto the same
-// queues, two chunks end up in one queue and wait for each other (C5: 52 ms -> 60-63 ms).  Eight queues remove that
-// (profiles/r02_e2e_chunking.txt).  The runtime reads the variable when it initialises, so this only helps when the library
-// is loaded before the first HIP call of the process (always true for a linked Rust / C++ caller); it never overrides a value
-// the user has set.
-__attribute__((constructor)) static void aln_prefer_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// queues, two chunks end up in one queue and wait for each other (C5: 52 ms -> 60-63 ms; eight queues remove that,
+// profiles/r02_e2e_chunking.txt).  The library does NOT touch the environment (it did in r02: a constructor that called setenv in
+// someone else's process): a host that runs other streams beside batch calls exports GPU_MAX_HW_QUEUES=8 itself before the HIP
+// runtime initialises -- bench.py and the test harness do ("Environment").
 
 static int fail(hipError_t e, const char *what)
 {

@@ -124,6 +124,68 @@ __device__ __forceinline__ uint32_t cell_tag(SC topH, SC leftH, SC diagH, SC s, 
     return tag;
 }
 
+// The f64 cell, instruction by instruction (every real-valued caller runs it: each HeuristicAligner iteration, heuristic/mod.rs:58-77,
+// the re-estimated PWMs of latent-repeat-search, engine/calc.rs:107-136).  Left to the compiler, `fmax` became a canonicalizing
+// v_max_f64 pair per operand, fabs a v_and, every select a pair of v_cndmask on register halves it had just moved together, and
+// the cell came to ~40 VALU instructions with 29 spilled registers.  Here: three adds, two maxes (NaN cannot occur: finite inputs, only
+// add / max), the two distances m - a, m - b through the neg modifier (m >= a, b: no abs), three compares against constants and
+// three selects of small constants for the tag.  The literal (max - x).abs() < f64::EPSILON of enums.rs:21-25 stays literal.
+template <int SEM>
+__device__ __forceinline__ uint32_t cell_tag_f64(double top, double left, double diag, double s, double negp, double &h, bool &zero)
+{
+    double a, b, c, m, da, db;
+    asm("v_add_f64 %0, %6, %9\n\t"
+        "v_add_f64 %1, %7, %9\n\t"
+        "v_add_f64 %2, %8, %10\n\t"
+        "v_max_f64 %3, %0, %1\n\t"
+        "v_max_f64 %3, %3, %2\n\t"
+        "v_add_f64 %4, %3, -%0\n\t"
+        "v_add_f64 %5, %3, -%1"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(m), "=&v"(da), "=&v"(db)
+        : "v"(top), "v"(left), "v"(diag), "v"(negp), "v"(s));
+    uint32_t tag = (db < DBL_EPSILON) ? 1u : 0u;
+    tag = (da < DBL_EPSILON) ? 2u : tag;                              // Top > Left > Diagonal
+    zero = (m == 0.0);
+    if (is_local<SEM>()) tag = zero ? 3u : tag;                       // enums.rs:37
+    h = m;
+    return tag;
+}
+
+__device__ __forceinline__ double max_f64_raw(double a, double b)
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// The R cells of one lane for one wave step, f64 (core semantics only: the legacy ones are i32).  zr0: the carried penalty of the
+// lane's first row is `del` (local: the cell above is Beginning -- or, for row 1, what the advice says; global: the very first cell).
+// The penalty of the rows below follows from the cell just computed (simple/mod.rs:88-92, :201-205).  tag0: the tag of the first row.
+template <int SEM, int R>
+__device__ __forceinline__ void cells_f64(double topIn, double &hdiag, double (&Hl)[R], const double (&sc)[R], bool zr0, double nd, double ne,
+                                          uint32_t &dw, double (&rbv)[R], uint32_t (&rbx)[R], uint32_t x, uint32_t &tag0)
+{
+    double top = topIn, diag = hdiag;
+    bool zr = zr0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double negp = zr ? nd : ne;
+        double h;
+        bool zero;
+        const uint32_t tag = cell_tag_f64<SEM>(top, Hl[r], diag, sc[r], negp, h, zero);
+        zr = (SEM == ALN_CORE_LOCAL) ? zero : false;
+        diag = Hl[r];
+        Hl[r] = h;
+        top = h;
+        dw = __builtin_amdgcn_alignbit(tag, dw, 2);                   // (dw >> 2) | (tag << 30)
+        if (SEM == ALN_CORE_LOCAL) {
+            rbx[r] = (h > rbv[r]) ? x : rbx[r];                         // first maximum of the row (simple/mod.rs:212)
+            rbv[r] = max_f64_raw(rbv[r], h);
+        }
+        if (r == 0) tag0 = tag;
+    }
+    hdiag = topIn;
+}
+
 // ---------------------------------------------------------------- per-wave state
 template <typename SC>
 struct Wave {
@@ -228,35 +290,44 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
             for (int r = 0; r < R; ++r) snext[r] = w.S[tc[r] + qoff];
             if (xm1 < N) {
                 const uint32_t x = xm1 + 1;
+                if constexpr (sizeof(SC) == 8 && is_core<SEM>()) {
+                    // row 1 (lane 0 of strip 0) takes its penalty from the advice / the first cell; every other first row from the cell above
+                    const bool row1 = (strip == 0 && lane == 0);
+                    const bool zr0 = (SEM == ALN_CORE_GLOBAL) ? (row1 && x == 1) : (row1 ? (x == 1 || adv != 0) : (topIn == (SC)0));
+                    uint32_t tag0 = 0;
+                    cells_f64<SEM, R>(topIn, hdiag, Hl, scur, zr0, -del, -ext, dw, rbv, rbx, x, tag0);
+                    if (SEM == ALN_CORE_LOCAL && strip == 0 && w.hazard && lane == 0) { w.row1[x] = Hl[0]; w.row1tag[x] = (uint8_t)tag0; }
+                } else {
                 SC top = topIn, diag = hdiag;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t y = yb + 1 + r;
-                    const SC s = scur[r];
-                    SC p;
-                    if (SEM == ALN_CORE_GLOBAL) {
-                        // penalty is `del` for the first visited cell only (simple/mod.rs:72,88-92)
-                        p = (r == 0 && y == 1 && x == 1) ? del : ext;
-                    } else if (SEM == ALN_CORE_LOCAL) {
-                        // carried penalty = del iff the previously visited cell was Beginning (H == 0):
-                        // the cell above for y >= 2; the BOTTOM cell of the previous column for y == 1 (advice)
-                        p = (top == (SC)0) ? del : ext;
-                        if (r == 0 && y == 1) p = (x == 1 || adv != 0) ? del : ext;
-                    } else {
-                        p = del;
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t y = yb + 1 + r;
+                        const SC s = scur[r];
+                        SC p;
+                        if (SEM == ALN_CORE_GLOBAL) {
+                            // penalty is `del` for the first visited cell only (simple/mod.rs:72,88-92)
+                            p = (r == 0 && y == 1 && x == 1) ? del : ext;
+                        } else if (SEM == ALN_CORE_LOCAL) {
+                            // carried penalty = del iff the previously visited cell was Beginning (H == 0):
+                            // the cell above for y >= 2; the BOTTOM cell of the previous column for y == 1 (advice)
+                            p = (top == (SC)0) ? del : ext;
+                            if (r == 0 && y == 1) p = (x == 1 || adv != 0) ? del : ext;
+                        } else {
+                            p = del;
+                        }
+                        SC h;
+                        const uint32_t tag = cell_tag<SC, SEM>(top, Hl[r], diag, s, p, h);
+                        diag = Hl[r];
+                        Hl[r] = h;
+                        top = h;
+                        dw = (dw >> 2) | (tag << 30);                           // same packing as v_alignbit in the fast path
+                        if (is_local<SEM>()) {
+                            const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
+                            rbv[r] = upd ? h : rbv[r];
+                            rbx[r] = upd ? x : rbx[r];
+                        }
+                        if (SEM == ALN_CORE_LOCAL && r == 0 && strip == 0 && w.hazard && lane == 0) { w.row1[x] = h; w.row1tag[x] = (uint8_t)tag; }
                     }
-                    SC h;
-                    const uint32_t tag = cell_tag<SC, SEM>(top, Hl[r], diag, s, p, h);
-                    diag = Hl[r];
-                    Hl[r] = h;
-                    top = h;
-                    dw = (dw >> 2) | (tag << 30);                           // same packing as v_alignbit in the fast path
-                    if (is_local<SEM>()) {
-                        const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
-                        rbv[r] = upd ? h : rbv[r];
-                        rbx[r] = upd ? x : rbx[r];
-                    }
-                    if (SEM == ALN_CORE_LOCAL && r == 0 && strip == 0 && w.hazard && lane == 0) { w.row1[x] = h; w.row1tag[x] = (uint8_t)tag; }
                 }
                 if (w.hmat != nullptr) {
 #pragma unroll
@@ -642,28 +713,36 @@ __device__ __forceinline__ void wg_strip(const WgArgs &a, const PairDesc &d, con
             for (int r = 0; r < R; ++r) snext[r] = sh.S[tc[r] + qoff];
             if (xm1 < N) {
                 const uint32_t x = xm1 + 1;
+                if constexpr (sizeof(SC) == 8 && is_core<SEM>()) {
+                    const bool row1 = (strip == 0 && lane == 0);
+                    const bool zr0 = (SEM == ALN_CORE_GLOBAL) ? (row1 && x == 1) : (row1 ? (x == 1 || adv != 0) : (topIn == (SC)0));
+                    uint32_t tag0 = 0;
+                    cells_f64<SEM, R>(topIn, hdiag, Hl, scur, zr0, -del, -ext, dw, rbv, rbx, x, tag0);
+                    if (SEM == ALN_CORE_LOCAL && strip == 0 && hazard && lane == 0) { sh.row1[x] = Hl[0]; sh.row1tag[x] = (uint8_t)tag0; }
+                } else {
                 SC top = topIn, diag = hdiag;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t y = yb + 1 + r;
-                    const SC sc = scur[r];
-                    SC p;
-                    if (SEM == ALN_CORE_GLOBAL) p = (r == 0 && y == 1 && x == 1) ? del : ext;
-                    else if (SEM == ALN_CORE_LOCAL) {
-                        p = (top == (SC)0) ? del : ext;
-                        if (r == 0 && y == 1) p = (x == 1 || adv != 0) ? del : ext;
-                    } else p = del;
-                    SC h;
-                    const uint32_t tag = cell_tag<SC, SEM>(top, Hl[r], diag, sc, p, h);
-                    diag = Hl[r];
-                    Hl[r] = h;
-                    top = h;
-                    dw = (dw >> 2) | (tag << 30);
-                    if (is_local<SEM>()) {           // (a branch here: the CU is issue-bound with its 8+ waves, and most cells update nothing)
-                        const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
-                        if (upd) { rbv[r] = h; rbx[r] = x; }
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t y = yb + 1 + r;
+                        const SC sc = scur[r];
+                        SC p;
+                        if (SEM == ALN_CORE_GLOBAL) p = (r == 0 && y == 1 && x == 1) ? del : ext;
+                        else if (SEM == ALN_CORE_LOCAL) {
+                            p = (top == (SC)0) ? del : ext;
+                            if (r == 0 && y == 1) p = (x == 1 || adv != 0) ? del : ext;
+                        } else p = del;
+                        SC h;
+                        const uint32_t tag = cell_tag<SC, SEM>(top, Hl[r], diag, sc, p, h);
+                        diag = Hl[r];
+                        Hl[r] = h;
+                        top = h;
+                        dw = (dw >> 2) | (tag << 30);
+                        if (is_local<SEM>()) {           // (a branch here: the CU is issue-bound with its 8+ waves, and most cells update nothing)
+                            const bool upd = (SEM == ALN_CORE_LOCAL) ? (h > rbv[r]) : (h >= rbv[r]);
+                            if (upd) { rbv[r] = h; rbx[r] = x; }
+                        }
+                        if (SEM == ALN_CORE_LOCAL && r == 0 && strip == 0 && hazard && lane == 0) { sh.row1[x] = h; sh.row1tag[x] = (uint8_t)tag; }
                     }
-                    if (SEM == ALN_CORE_LOCAL && r == 0 && strip == 0 && hazard && lane == 0) { sh.row1[x] = h; sh.row1tag[x] = (uint8_t)tag; }
                 }
                 if (hmat != nullptr) {
 #pragma unroll
@@ -1210,6 +1289,7 @@ __device__ __forceinline__ bool pair_codes_ok(const uint8_t *seqs, const PairDes
     for (uint32_t i = (uint32_t)lane; i < d.M; i += 64u) worst_t = max(worst_t, (uint32_t)t[i]);
     return !__any(worst_q >= cols || worst_t >= rows);
 }
+// (f64: two workgroups per CU -- 256 registers per lane: eight rows of f64 state, scores and trackers spilled at 168)
 template <typename SC, int SEM>
 __global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
 {

@@ -399,6 +399,58 @@ def test_single_pair_route_repairs_the_row1_hazard_locally(orc, blosum62, monkey
     assert seen_repair >= 2, seen_repair
 
 
+def _same_batch_results(a, b, n, strings_every=1):
+    assert (a.results["status"] == b.results["status"]).all()
+    for f in ("score", "f", "end_y", "end_x", "start_y", "start_x", "aln_len"):
+        assert (a.results[f] == b.results[f]).all(), f
+    for i in range(0, n, strings_every):
+        qa, ta = a.aligned(i)
+        qb, tb = b.aligned(i)
+        assert (qa == qb).all() and (ta == tb).all(), i
+
+
+def test_batch_of_large_pairs_shares_the_strips_of_a_pair(orc, blosum62, monkeypatch):
+    """256 pairs of 4200 x 4200 (1.8e7 cells each: above the old 2^24-cell line every one of them took the single-pair route, one
+    after the other).  The batch kernel now takes them -- fewer pairs than resident waves, so the waves without a pair claim strips
+    of other waves' pairs (cooperative passes, first passes included).  All 256 against the same batch filled with one wave per
+    pair (ALN_NO_COOP), 16 of them against the oracle; a second, smaller batch goes the same way with hints suppressed (every
+    open pass filled by its owner alone through the shared-pass code) and with every re-fill shared."""
+    import threading
+    b = workloads.c5_batch(n_pairs=256, lo=4200, hi=4200)
+    got = align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    assert (got.results["status"] == 0).all()
+    assert ((got.results["flags"] & 2) == 0).all()                           # not the single-pair route
+    monkeypatch.setenv("ALN_NO_COOP", "1")
+    monkeypatch.setenv("ALN_BIG_TO_SINGLE", "0")
+    solo = align_batch(b, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    monkeypatch.delenv("ALN_NO_COOP")
+    monkeypatch.delenv("ALN_BIG_TO_SINGLE")
+    _same_batch_results(got, solo, len(b))
+    sample = list(range(0, 256, 16))
+    refs = [None] * len(sample)
+
+    def run(j):
+        i = sample[j]
+        refs[j] = orc.align(orc.CORE_LOCAL, b.query(i), b.target(i), 11, 2, blosum62)
+    th = [threading.Thread(target=run, args=(j,)) for j in range(len(sample))]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    for j, i in enumerate(sample):
+        r, g = refs[j], got.results[i]
+        assert (g["score"], g["end_y"], g["end_x"], g["start_y"], g["start_x"]) == (r["score"], r["end"][0], r["end"][1], r["start"][0], r["start"][1]), i
+        qa, ta = got.aligned(i)
+        assert qa.tolist() == r["qa"].tolist() and ta.tolist() == r["ta"].tolist(), i
+    # the shared-pass code with nobody to share with, and with every re-fill shared whatever the queue holds
+    small = workloads.c5_batch(n_pairs=1500, lo=200, hi=2000)
+    base = _check_batch(orc, small, _ffi.CORE_LOCAL, 11, 2, blosum62)
+    for dbg in ("2", "8"):
+        monkeypatch.setenv("ALN_COOP_DEBUG", dbg)
+        _same_batch_results(align_batch(small, _ffi.CORE_LOCAL, 11, 2, blosum62), base, len(small), strings_every=7)
+    monkeypatch.delenv("ALN_COOP_DEBUG")
+    # core global has no re-fills, only first passes to share
+    _check_batch(orc, workloads.c5_batch(n_pairs=400, lo=600, hi=1800), _ffi.CORE_GLOBAL, 11, 2, blosum62)
+
+
 def test_long_pairs_beyond_the_old_column_limit(orc, blosum62):
     """The single-pair route stages the whole query's profile offsets in LDS.  Up to r01 the host refused it above a 64 KiB
     budget (N ~ 29 400 columns) and such a pair fell to the one-wave batch kernel; a workgroup now opts in to the CU's whole

@@ -7,6 +7,8 @@ import time
 
 import numpy as np
 
+# eight hardware queues for the pipeline's four streams (the library no longer sets this itself; INTEGRATION.md, "Environment")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aligner_amd import _ffi, runtime, workloads  # noqa: E402
 from aligner_amd.batch import RESULT_DTYPE  # noqa: E402
