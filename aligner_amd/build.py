@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libaligner_hip.so")
 SOURCES = ["aln_kernels.hip", "aln_host.hip"]
 # aln_kernels.hip is compiled as several translation units side by side (-DALN_TU=<mask of its ALN_PART_* families>): the fast
 # core-local batch kernel alone is half of the compile time
-KERNEL_UNITS = [("generic", 1), ("fast_cl", 2), ("fast_rest", 4), ("single", 8), ("tb", 16)]
+KERNEL_UNITS = [("generic", 1), ("fast_cl", 2), ("fast_rest", 4), ("single", 8), ("tb", 16), ("fast_cl_solo", 32), ("fast_rest_solo", 64)]
 HEADERS = ["aln_device.h", "aln_fast.h", "aln_single_unit.inc", os.path.join("..", "..", "include", "aligner_hip.h")]
 # host-only helper of the synthetic workloads (splitmix64 residues; aligner_amd/workloads.py only LOADS it)
 SYNTH_LIB = os.path.join(LIBDIR, "libaln_synth.so")

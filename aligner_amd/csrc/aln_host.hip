@@ -582,10 +582,20 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
     }
     // Cooperative passes: waves without a pair of their own take strips of other waves' pairs, so a batch with fewer pairs than
     // resident waves still gets as many waves as it has strips
-    k.coop = coop_on && k.n_small != 0;
+    // (nothing to share in a batch whose pairs all have one strip -- read pairs, PWM windows, the p-value batch: the kernel then runs
+    // exactly as without the machinery)
+    uint64_t strips = 0, multi = 0;
+    for (size_t j = 0; j < k.n_small; ++j) {
+        const PairDesc &d = k.descs[k.order[j]];
+        // (a pair has something to share when its first pass has several strips, or when it may be re-filled -- core local with
+        // del != ext -- and is large enough for that re-fill to matter: a 330 x 300 window is through in 40 us either way)
+        if (d.status == ALN_OK) {
+            strips += aln_num_strips(d.M);
+            multi += (d.M > ALN_STRIP_ROWS || (c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext && d.M > 64u && (uint64_t)d.N * d.M >= (1u << 18))) ? 1u : 0u;
+        }
+    }
+    k.coop = coop_on && k.n_small != 0 && multi != 0;
     if (k.coop) {
-        uint64_t strips = 0;
-        for (size_t j = 0; j < k.n_small; ++j) { const PairDesc &d = k.descs[k.order[j]]; if (d.status == ALN_OK) strips += aln_num_strips(d.M); }
         const uint32_t resident = (uint32_t)ctx->cus * 3u;
         // (allow_overlap == false: a chunk of a pipelined call -- the chunks before and after it share the chip with this one, so its
         // grid stays at one wave per pair, nobody lingers, and only re-fills are shared)

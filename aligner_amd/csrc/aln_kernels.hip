@@ -27,12 +27,14 @@
 // The file is compiled as several translation units in parallel (aligner_amd/build.py: -DALN_TU=<mask>), each instantiating one
 // family of kernels together with the launch helpers that name them; the templates themselves are seen by every unit.
 #define ALN_PART_GENERIC 1     // generic fill kernels (int32 without the profile, f64), one-workgroup route, validation
-#define ALN_PART_FAST_CL 2     // fast integer batch kernel, core local
-#define ALN_PART_FAST_REST 4   // fast integer batch kernels: core local with PWM scoring, core global, legacy
+#define ALN_PART_FAST_CL 2     // fast integer batch kernel, core local, with the cooperative passes
+#define ALN_PART_FAST_REST 4   // fast integer batch kernels with the cooperative passes: core local with PWM scoring, core global, legacy
+#define ALN_PART_FAST_CL_SOLO 32      // the same two without (batches that have nothing to share)
+#define ALN_PART_FAST_REST_SOLO 64
 #define ALN_PART_SINGLE 8      // single-pair (strip-pipelined) route
 #define ALN_PART_TB 16         // traceback + direction unpack
 #ifndef ALN_TU
-#define ALN_TU 31
+#define ALN_TU 127
 #endif
 
 namespace {
@@ -951,7 +953,7 @@ __device__ __forceinline__ bool coop_find(const CoopCtx &c, bool urgent_only, in
 // carries the lane candidates along) or on any wave that claimed it (open: `o` starts empty and the strip's candidate goes to the
 // owner's record).  `in` arrives with this wave's constants (lane, S, profile, penalties); everything about the pair is set here.
 // Ru: 0 = skewed layout, else uniform strips of 64 Ru rows; own: strip 0's bottom row keeps row 0 to itself.
-template <int SEM, bool PWM>
+template <int SEM, bool PWM, bool COOP>
 __device__ __forceinline__ void coop_run_strip(FastIn in, const FillArgs &a, uint32_t pair, uint32_t ns, uint32_t Ru, uint32_t own, uint32_t tag,
                                                uint32_t owner, CoopRec *rec, uint32_t s, FastOut &o, bool open, int del, int ext)
 {
@@ -967,7 +969,9 @@ __device__ __forceinline__ void coop_run_strip(FastIn in, const FillArgs &a, uin
     in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0;
     in.ck_mode = 0; in.last_flip = 0; in.ck_stop = 0;
     in.store_dirs = a.store_dirs != 0;
-    in.wt_dirs = a.doneq != nullptr || a.coop != nullptr;
+    // direction quads of a shared pass are stored write-through: its strips run on other XCDs, and lines that sit dirty in two L2s
+    // are written back in any order (fast_work fences before it opens a re-fill over a first pass stored the ordinary way)
+    in.wt_dirs = a.doneq != nullptr || open;
     in.pwm = a.pwm != 0;
     in.pwm_words = a.pwm_words;
     in.advice = fs.advice; in.zrow = fs.zrow; in.ckpt = fs.ckpt;
@@ -984,8 +988,8 @@ __device__ __forceinline__ void coop_run_strip(FastIn in, const FillArgs &a, uin
     const int R = Ru ? (int)Ru : (last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R);
     if (open) { o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0; }
     o = fast_strip_next<SEM, PWM>(in, o, s, last, R);
-    if (o.aborted && a.coop && in.lane == 0) __hip_atomic_fetch_add(a.coop + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((a.coop_debug & 128u) && a.coop && !last) {        // testing: does the row this strip leaves behind carry its tag in every column?
+    if (COOP && o.aborted && a.coop && in.lane == 0) __hip_atomic_fetch_add(a.coop + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (COOP && (a.coop_debug & 128u) && a.coop && !last) {        // testing: does the row this strip leaves behind carry its tag in every column?
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t bad = 0;
         for (uint32_t x = 1 + in.lane; x <= N; x += 64)
@@ -1021,7 +1025,10 @@ __device__ __forceinline__ void coop_run_strip(FastIn in, const FillArgs &a, uin
 // (helper == true: a pair somebody else owns).  ONE function, so that the strips below strip 0 are instantiated at one place
 // whoever runs them.  epoch: this wave's count of multi-strip passes in this launch (the seq of their tags).
 // Returns true when the pair's directions were written with ordinary stores (the strict-order fallback).
-template <int SEM, bool PWM>
+// COOP = false: the kernel variant for batches that have nothing to share (every pair one strip and no re-fill worth sharing: read
+// pairs, PWM windows, the p-value batch) -- none of the machinery is compiled in, and the wave keeps far less state alive around
+// a strip (with it, the 150 x 150 read pairs of C3 paid 100 scratch stores and loads per pair: 12 % of their fill).
+template <int SEM, bool PWM, bool COOP>
 __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, const CoopCtx &cp, const FillArgs &a, const bool helper, const uint32_t w,
                                           uint32_t pair, const uint32_t qpos, uint32_t &epoch, int del, int ext)
 {
@@ -1040,7 +1047,7 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
         in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0;
         in.ck_mode = 0; in.last_flip = 0; in.ck_stop = 0;
         in.store_dirs = a.store_dirs != 0;
-        in.wt_dirs = a.doneq != nullptr || a.coop != nullptr;   // (cooperative passes: a re-fill may rewrite, from another XCD, lines this XCD's L2 still holds)
+        in.wt_dirs = a.doneq != nullptr;
         in.pwm = a.pwm != 0;
         in.pwm_words = a.pwm_words;
         in.advice = fs.advice; in.zrow = fs.zrow; in.ckpt = fs.ckpt;
@@ -1052,8 +1059,8 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
         // repairable: strip 0's bottom row stays as the checkpointed pass wrote it (row 0); the strips below alternate between rows 1 and 2
         can_repair = in.hazard && !a.no_repair && (ns_skew == 1 || fs.nrows >= 3);
     }
-    CoopRec *rec = cp.ctl ? cp.recs + (helper ? w : cp.wave) : nullptr;
-    bool coop_ok = cp.ctl != nullptr;                    // cleared when a cooperative pass had to give up: the rest runs on this wave alone
+    CoopRec *rec = (COOP && cp.ctl) ? cp.recs + (helper ? w : cp.wave) : nullptr;
+    bool coop_ok = COOP && cp.ctl != nullptr;                    // cleared when a cooperative pass had to give up: the rest runs on this wave alone
     uint32_t passes = 0, Ru = 0, tag = 0, ns = 0, own = 0;
     bool converged = false, device_error = false, open = helper;
     FastOut o;
@@ -1082,7 +1089,13 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
             }
             tag = aln_coop_tag(a.salt, epoch);
             open = share && ns >= 2 && ns <= ALN_COOP_MAX_NS;
-            if (open) coop_open(cp, lane, pair, tag, epoch, ns, Ru, own, passes != 0, !(a.coop_debug & 2u));
+            if (open) {
+                // the strips of this pass may be stored from other XCDs: nothing the earlier passes of this pair stored the ordinary
+                // way may still sit dirty in this XCD's L2 (it would be written back over them at some later time)
+                if (passes != 0 && a.doneq == nullptr) __threadfence();
+                coop_open(cp, lane, pair, tag, epoch, ns, Ru, own, passes != 0, !(a.coop_debug & 2u));
+            }
+            in.wt_dirs = a.doneq != nullptr || open;
             o.bv = INT_MIN; o.by = 0; o.bx = 0; o.corner = 0; o.repaired = false; o.brow_bad = false; o.aborted = false; o.ck_slot = 0; o.c_out = 0;
             in.brow_in = fs.rows; in.brow_out = fs.rows;
             in.strip_rows = srows;
@@ -1127,7 +1140,7 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
                 if (s >= ns) break;
                 ++snext;
             }
-            coop_run_strip<SEM, PWM>(in, a, pair, ns, Ru, own, tag, helper ? w : cp.wave, rec, s, o, open, del, ext);
+            coop_run_strip<SEM, PWM, COOP>(in, a, pair, ns, Ru, own, tag, helper ? w : cp.wave, rec, s, o, open, del, ext);
         }
         if (helper) return false;
         bool pass_bad = false;
@@ -1325,7 +1338,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
     }
 }
 
-template <int SEM, bool PWM>
+template <int SEM, bool PWM, bool COOP>
 // 160 VGPRs, not the 168 that three waves per SIMD would allow (the attribute counts pairs on gfx90a+): the 32 registers
 // left over on every SIMD hold one wave of the walk kernel that runs beside the fill.
 __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(3, 3), amdgpu_num_vgpr(80)))
@@ -1341,7 +1354,9 @@ void aln_fill_fast_kernel(FillArgs a)
     in.lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const FastScratch fs = fast_scratch(a, wave);
-    const CoopCtx cp = coop_ctx(a, wave);
+    CoopCtx cp;
+    if constexpr (COOP) cp = coop_ctx(a, wave);
+    else { cp.ctl = nullptr; cp.words = nullptr; cp.nw = 0; cp.nw_pad = 0; cp.recs = nullptr; cp.wave = wave; }
     in.brow_in = fs.rows; in.brow_out = fs.rows;
     in.advice = fs.advice;
     in.zrow = fs.zrow;
@@ -1363,17 +1378,17 @@ void aln_fill_fast_kernel(FillArgs a)
         // else the next pair of the queue, else (the queue is dry) wait for either
         bool all_done = false, helper = false;
         uint32_t w = 0;
-        if (cp.ctl) helper = coop_find(cp, !dry, in.lane, w, all_done, a.n_pairs);
+        if (COOP && cp.ctl) helper = coop_find(cp, !dry, in.lane, w, all_done, a.n_pairs);
         if (!helper) {
             if (!dry && !next_pair(a, in.lane, pair, qpos)) {
                 dry = true;
-                if (cp.ctl) continue;                    // first passes of other waves' pairs next
+                if (COOP && cp.ctl) continue;            // first passes of other waves' pairs next
             }
             if (dry) {
                 // nobody has a strip to give away right now: stay while pairs are still being filled -- any of them may yet need a
                 // second pass -- but look rarely (a few thousand idle waves polling one line every few microseconds slowed the
                 // waves that still work by 20 %)
-                if (!cp.ctl || !a.coop_linger || all_done) break;
+                if (!COOP || !cp.ctl || !a.coop_linger || all_done) break;
                 if (idle_since == 0) idle_since = wall_clock64();
                 else if (wall_clock64() - idle_since > 200000000ull) break;        // 2 s of nothing: leave
                 __builtin_amdgcn_s_setprio(0);
@@ -1386,7 +1401,7 @@ void aln_fill_fast_kernel(FillArgs a)
             if (bad_shape || !pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, in.lane)) {
                 skip_invalid(res, bad_shape ? desc.status : ALN_ERR_CODE_OUT_OF_RANGE, in.lane);
                 pair_done(a, in.lane, pair, false);
-                if (cp.ctl && in.lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_FINISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (COOP && cp.ctl && in.lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_FINISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 continue;
             }
             set_wave_priority((uint64_t)desc.N * desc.M, a.max_cells);
@@ -1396,13 +1411,13 @@ void aln_fill_fast_kernel(FillArgs a)
         const uint64_t ts = wall_clock64();
 #endif
         // (one call for both: the strips below strip 0 are the same code whoever runs them)
-        const bool plain = fast_work<SEM, PWM>(in, fs, cp, a, helper, w, pair, qpos, epoch, (int)a.del, (int)a.ext);
+        const bool plain = fast_work<SEM, PWM, COOP>(in, fs, cp, a, COOP && helper, w, pair, qpos, epoch, (int)a.del, (int)a.ext);
         if (helper) continue;
 #ifdef ALN_STAMPS
         if (in.lane == 0) { aln_pair_result &res = a.results[pair]; res.aln_len = (uint32_t)ts; res.start_x = (uint32_t)wall_clock64(); res.start_y = wave; }
 #endif
         pair_done(a, in.lane, pair, plain);
-        if (cp.ctl && in.lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_FINISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (COOP && cp.ctl && in.lane == 0) __hip_atomic_fetch_add(cp.ctl + ALN_COOP_FINISHED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2355,34 +2370,53 @@ extern "C" __global__ void aln_unpack_directions_kernel(const uint8_t *dirs, con
 #endif   // ALN_PART_TB
 
 // ---------------------------------------------------------------- launch helpers used by aln_host.hip
+#define ALN_FAST_REST_LAUNCH(COOPV)                                                                                        \
+    switch (a->semantics) {                                                                                                \
+    case ALN_CORE_GLOBAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_GLOBAL, false, COOPV>), g, b, lds_bytes, s, *a); break; \
+    case ALN_CORE_LOCAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, true, COOPV>), g, b, lds_bytes, s, *a); break;   /* PWM scoring */ \
+    case ALN_LEGACY_GLOBAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_LEGACY_GLOBAL, false, COOPV>), g, b, lds_bytes, s, *a); break; \
+    default: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_LEGACY_LOCAL, false, COOPV>), g, b, lds_bytes, s, *a); break;      \
+    }
 #if ALN_TU & ALN_PART_FAST_CL
 extern "C" void aln_launch_fill_fast_cl(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, false>), dim3(grid), dim3(256), lds_bytes, s, *a);
+    hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, false, true>), dim3(grid), dim3(256), lds_bytes, s, *a);
+}
+#endif
+#if ALN_TU & ALN_PART_FAST_CL_SOLO
+extern "C" void aln_launch_fill_fast_cl_solo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, false, false>), dim3(grid), dim3(256), lds_bytes, s, *a);
 }
 #endif
 #if ALN_TU & ALN_PART_FAST_REST
 extern "C" void aln_launch_fill_fast_rest(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), b(256);
-    switch (a->semantics) {
-    case ALN_CORE_GLOBAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_GLOBAL, false>), g, b, lds_bytes, s, *a); break;
-    case ALN_CORE_LOCAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_CORE_LOCAL, true>), g, b, lds_bytes, s, *a); break;   // PWM scoring
-    case ALN_LEGACY_GLOBAL: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_LEGACY_GLOBAL, false>), g, b, lds_bytes, s, *a); break;
-    default: hipLaunchKernelGGL((aln_fill_fast_kernel<ALN_LEGACY_LOCAL, false>), g, b, lds_bytes, s, *a); break;
-    }
+    ALN_FAST_REST_LAUNCH(true)
 }
 #endif
+#if ALN_TU & ALN_PART_FAST_REST_SOLO
+extern "C" void aln_launch_fill_fast_rest_solo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
+{
+    const dim3 g(grid), b(256);
+    ALN_FAST_REST_LAUNCH(false)
+}
+#endif
+#undef ALN_FAST_REST_LAUNCH
 #if ALN_TU & ALN_PART_GENERIC
 extern "C" void aln_launch_fill_fast_cl(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_fill_fast_rest(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
+extern "C" void aln_launch_fill_fast_cl_solo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
+extern "C" void aln_launch_fill_fast_rest_solo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), b(256);
 #define ALN_LAUNCH(SC, SEM) hipLaunchKernelGGL((aln_fill_kernel<SC, SEM>), g, b, lds_bytes, s, *a)
     if (is_int && fast) {
-        if (a->semantics == ALN_CORE_LOCAL && !a->pwm) aln_launch_fill_fast_cl(a, grid, lds_bytes, s);
-        else aln_launch_fill_fast_rest(a, grid, lds_bytes, s);
+        const bool cl = a->semantics == ALN_CORE_LOCAL && !a->pwm;
+        if (a->coop) { if (cl) aln_launch_fill_fast_cl(a, grid, lds_bytes, s); else aln_launch_fill_fast_rest(a, grid, lds_bytes, s); }
+        else { if (cl) aln_launch_fill_fast_cl_solo(a, grid, lds_bytes, s); else aln_launch_fill_fast_rest_solo(a, grid, lds_bytes, s); }
     } else if (is_int) {
         switch (a->semantics) {
         case ALN_CORE_GLOBAL: ALN_LAUNCH(int, ALN_CORE_GLOBAL); break;

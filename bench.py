@@ -205,7 +205,111 @@ def small_configs(S, local_rank, stream, torch):
                  "traceback_ms": round(tm["traceback_ms"], 4), "fill_only_gcups": round(b3.cells / tm["fill_ms"] / 1e6, 2),
                  "alg_bytes_per_launch": alg, "alg_hbm_gbs": round(alg / (tm["fill_ms"] / 1e3) / 1e9, 2),
                  "direction_bytes_stored": dirs, "pairs_ok": int((r["status"] == 0).sum())}
+    # the reference's one batch driver: calculate_p_value (statistics/mod.rs:240-307) -- one 350-aa query against 4 999 shuffled
+    # copies of a 350-aa target, core local, score only (only alignment.f is kept, :273-279); host buffers in and out, the CPU
+    # oracle on the same pairs beside it (all host cores, as the reference's ten threads)
+    import oracle
+    from aligner_amd.statistics import shuffled_scores
+    rngp = np.random.default_rng(350)
+    qp, tp = rngp.integers(0, 20, 350).astype(np.uint8), rngp.integers(0, 20, 350).astype(np.uint8)
+    _, _, pb = shuffled_scores(qp, tp, 0.0, 11, 2, S, rng=np.random.default_rng(1), device=local_rank)
+    pp, keep_p = runtime.make_params(_ffi.CORE_LOCAL, 11, 2, S, outputs=_ffi.OUT_SCORE)
+    from aligner_amd.batch import RESULT_DTYPE
+    lib = _ffi.load()
+    ctxp = runtime.context(local_rank)
+    resp = np.zeros(len(pb), dtype=RESULT_DTYPE)
+    tsp = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        st = lib.aln_align_batch(ctxp, C.byref(pp), pb.seqs.ctypes.data, pb.q_off.ctypes.data, pb.q_len.ctypes.data, pb.t_off.ctypes.data,
+                                 pb.t_len.ctypes.data, len(pb), resp.ctypes.data, None, None)
+        tsp.append(time.perf_counter() - t0)
+        runtime.raise_for_status(st, "aln_align_batch")
+    dtp = sorted(tsp[1:])[len(tsp[1:]) // 2]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    refp, _, _ = oracle.align_batch(oracle.CORE_LOCAL, pb.seqs, pb.q_off, pb.q_len, pb.t_off, pb.t_len, 11, 2, S, max(1, min(cores, 64)))
+    dto = time.perf_counter() - t0
+    out["p_value_batch"] = {"workload": "calculate_p_value's batch: one 350-aa query x 4999 shuffled 344..350-aa targets, core local, BLOSUM62 11/2, "
+                                        "score only, host buffers in and out (one aln_align_batch call)",
+                            "ms": round(dtp * 1e3, 3), "gcups": round(pb.cells / dtp / 1e9, 2),
+                            "cpu_oracle_ms": round(dto * 1e3, 1), "cpu_oracle_threads": max(1, min(cores, 64)),
+                            "scores_equal_oracle": bool(all(float(resp[i]["f"]) == refp[i].f for i in range(len(pb))))}
+    # batches of LARGE pairs (r02: every pair of >= 2^24 cells took the single-pair route, one after the other): 256 pairs of
+    # 4200 x 4200 through aln_align_batch, host buffers in and out -- the batch kernel shares the strips of a pair between waves
+    bb = workloads.c5_batch(n_pairs=256, lo=4200, hi=4200)
+    pbig, keep_b = runtime.make_params(_ffi.CORE_LOCAL, 11, 2, S, outputs=_ffi.OUT_SCORE | _ffi.OUT_TRACEBACK)
+    resb = np.zeros(len(bb), dtype=RESULT_DTYPE)
+    tbo, tbt = bb.tb_layout()
+    tbb = np.zeros(max(tbt, 1), dtype=np.uint8)
+    tsb = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        st = lib.aln_align_batch(ctxp, C.byref(pbig), bb.seqs.ctypes.data, bb.q_off.ctypes.data, bb.q_len.ctypes.data, bb.t_off.ctypes.data,
+                                 bb.t_len.ctypes.data, len(bb), resb.ctypes.data, tbb.ctypes.data, tbo.ctypes.data)
+        tsb.append(time.perf_counter() - t0)
+        runtime.raise_for_status(st, "aln_align_batch")
+    dtb = min(tsb[1:])
+    out["large_pairs_batch"] = {"workload": "256 protein pairs of 4200 x 4200 (1.8e7 cells each), core local, BLOSUM62 11/2, summaries + both strings, "
+                                            "host buffers in and out",
+                                "ms": round(dtb * 1e3, 3), "gcups": round(bb.cells / dtb / 1e9, 2),
+                                "pairs_on_single_pair_route": int(((resb["flags"] & 2) != 0).sum()), "pairs_ok": int((resb["status"] == 0).sum())}
+    # a batch with a real-valued matrix (f64 kernels): the first 20000 C5 pairs, BLOSUM62 x 0.5, 11.5 / 2.25, host to host
+    from aligner_amd.batch import align_batch
+    bf = workloads.c5_batch(20000)
+    tsf = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rf = align_batch(bf, _ffi.CORE_LOCAL, 11.5, 2.25, S * 0.5, device=local_rank, want_traceback=True)
+        tsf.append(time.perf_counter() - t0)
+    out["f64_batch"] = {"workload": "the first 20000 C5 pairs, real-valued matrix (BLOSUM62 x 0.5, del 11.5 / ext 2.25): f64 kernels, summaries + strings, host to host",
+                        "ms": round(min(tsf[1:]) * 1e3, 2), "gcups": round(bf.cells / min(tsf[1:]) / 1e9, 2), "pairs_ok": int((rf.results["status"] == 0).sum())}
     return out
+
+
+def cold_start():
+    """What a one-shot caller sees (aligner-cli aligns ONE pair per process, aligner-cli/main.rs:41-53): context creation, the
+    first pair and the first batch of a fresh process -- measured in a child process without torch."""
+    import subprocess
+    code = r"""
+import ctypes as C, json, os, sys, time
+import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, %r)
+t0 = time.perf_counter()
+from aligner_amd import _ffi, runtime, workloads
+from aligner_amd.batch import align_batch
+from aligner_amd.matrices import get_blosum62
+S = get_blosum62()
+t_import = time.perf_counter() - t0
+t0 = time.perf_counter(); ctx = runtime.context(0); t_create = time.perf_counter() - t0
+q, t = workloads.c2_pair(homolog=False)
+t0 = time.perf_counter(); runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, S); t_pair1 = time.perf_counter() - t0
+t0 = time.perf_counter(); runtime.align_pair(_ffi.CORE_LOCAL, q, t, 11, 2, S); t_pair2 = time.perf_counter() - t0
+b = workloads.c5_batch(100000)
+t0 = time.perf_counter(); align_batch(b, _ffi.CORE_LOCAL, 11, 2, S); t_b1 = time.perf_counter() - t0
+t0 = time.perf_counter(); align_batch(b, _ffi.CORE_LOCAL, 11, 2, S); t_b2 = time.perf_counter() - t0
+print("COLD " + json.dumps({"aln_create_ms": round(t_create * 1e3, 2), "first_1k_pair_ms": round(t_pair1 * 1e3, 2), "second_1k_pair_ms": round(t_pair2 * 1e3, 3),
+                            "first_c5_batch_call_ms": round(t_b1 * 1e3, 1), "second_c5_batch_call_ms": round(t_b2 * 1e3, 1)}))
+""" % ROOT
+    try:
+        outp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+        for ln in outp.splitlines():
+            if ln.startswith("COLD "):
+                d = json.loads(ln[5:])
+                d["what"] = "a fresh process (no torch): aln_create, first and second aln_align_pair of the C2 pair, first and second aln_align_batch of C5 (Python wrapper included)"
+                return d
+    except Exception as e:                               # noqa: BLE001
+        return {"error": str(e)[:200]}
+    return {"error": "no output"}
+
+
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("aln_kernels.hip", "aln_fast.h", "aln_device.h"):
+        h.update(open(os.path.join(ROOT, "aligner_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -318,6 +422,7 @@ def main():
         alg_bytes = ALG_BYTES_PER_CELL * batch.cells + float((batch.q_len + batch.t_len).sum()) + 48.0 * len(batch)
         achieved = alg_bytes / fill_s / 1e9
         traffic = valu_insts = lds_ratio = None
+        pmc_fresh = False
         try:
             with open(args.traffic_json) as f:
                 tj = json.load(f)
@@ -325,8 +430,31 @@ def main():
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             valu_insts = tj.get(key, {}).get("valu_wave_insts_per_launch")
             lds_ratio = tj.get(key, {}).get("lds_bank_conflict_ratio")
+            pmc_fresh = tj.get(key, {}).get("kernel_src_sha16") == kernel_sources_sha16()
         except Exception:
             traffic = valu_insts = lds_ratio = None
+        # The binding roof of this integer DP is VALU issue, not HBM (HBM runs at ~8 % of its peak).  With the PMC count of
+        # the kernel's wave instructions per launch at hand the line is priced against that roof: achieved = instructions per launch
+        # / the kernel time measured live in this run, peak = the issue rate of the kernel's own instruction mix -- 10 of a cell's 11
+        # VALU instructions are in gfx950's 4-cycle class (profiles/r02_valu_rate.txt): 1024 SIMDs x 2.4 GHz / 4 = 614.4 G/s.
+        # Without the count (no PMC record for this batch size) the line falls back to the HBM form.
+        hbm = {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+               "alg_bytes_per_launch": alg_bytes, "traffic_over_alg": (round(traffic / alg_bytes, 3) if traffic else None)}
+        if valu_insts:
+            roof = {"bound": "valu", "achieved": round(valu_insts / fill_s / 1e9, 3), "peak": 614.4, "unit": "G wave-instructions/s",
+                    "frac": round(valu_insts / fill_s / 614.4e9, 4), "valu_insts_per_cell": round(valu_insts * 64.0 / batch.cells, 3),
+                    "valu_fullrate_frac": round(valu_insts / fill_s / 1228.8e9, 4)}
+        else:
+            roof = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"]}
+        roof.update({"kernel": "aln_fill_fast_kernel<CORE_LOCAL>", "traffic": traffic, "hbm": hbm,
+                     # the PMC figures (traffic, instruction count, LDS ratio) come from profiles/hbm_traffic.json; stale = the kernel
+                     # sources have changed since they were measured
+                     "pmc_figures_match_current_sources": pmc_fresh,
+                     "kernel_ms": round(timing["fill_ms"], 4), "traceback_ms": round(timing["traceback_ms"], 4),
+                     "fill_only_gcups_rank0": round(batch.cells / fill_s / 1e9, 3), "direction_bytes_stored": sb.direction_bytes,
+                     "lds_bank_conflict_ratio": lds_ratio,     # SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (PMC pass)
+                     # SURVEY's accounting: 16 lane-ops per cell against 78.6 T lane-ops/s (every instruction at the 2-cycle rate)
+                     "valu_frac_survey_accounting": round(batch.cells / fill_s * 16 / 78.6e12, 5)})
         line = {
             "metric": "GCUPS (DP cell updates/s), fill + traceback, inputs resident in HBM",
             "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -336,25 +464,7 @@ def main():
                                    "BLOSUM62, del 11 / ext 2, seed 0xA11C0005" % args.pairs,
                        "pairs": args.pairs, "cells": total_cells, "sharding": "LPT by cells over %d rank(s)" % world,
                        "pairs_ok_rank0": ok, "pairs_repaired_or_refilled_rank0": refills},
-            "roofline": {"bound": "hbm", "kernel": "aln_fill_fast_kernel<CORE_LOCAL>",
-                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": round(timing["fill_ms"], 4),
-                         "traceback_ms": round(timing["traceback_ms"], 4),
-                         "fill_only_gcups_rank0": round(batch.cells / fill_s / 1e9, 3),
-                         "direction_bytes_stored": sb.direction_bytes,
-                         "traffic_over_alg": (round(traffic / alg_bytes, 3) if traffic else None),
-                         "lds_bank_conflict_ratio": lds_ratio,     # SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (PMC pass)
-                         # HBM is not what binds this integer DP; VALU issue is.  valu_frac: SURVEY's accounting,
-                         # 16 lane-ops per cell against 78.6 T lane-ops/s (every instruction at the 2-cycle rate).
-                         "binding_roof": "valu_issue",
-                         "valu_frac": round(batch.cells / fill_s * 16 / 78.6e12, 5),
-                         # valu_issue_frac: PMC-counted wave instructions per launch / kernel time against the roof of the
-                         # kernel's own instruction mix -- 10 of a cell's 11 VALU instructions are in gfx950's 4-cycle class
-                         # (measured per instruction: profiles/r02_valu_rate.txt): 1024 SIMDs x 2.4 GHz / 4 = 614.4 G/s.
-                         # valu_fullrate_frac: the same count against the 2-cycle roof (1228.8 G/s).
-                         "valu_issue_frac": (round(valu_insts / fill_s / 614.4e9, 4) if valu_insts else None),
-                         "valu_fullrate_frac": (round(valu_insts / fill_s / 1228.8e9, 4) if valu_insts else None)},
+            "roofline": roof,
             # never `value`: the staged API's own hand-over costs (aln_batch_create = allocations + H2D; aln_batch_fetch = D2H of
             # every summary and string), serial around one step.  The pipelined host-buffer call is "end_to_end" below.
             "pcie_inclusive": {"stage_ms": round(t_stage * 1e3, 2), "fetch_ms": round(t_fetch * 1e3, 2),
@@ -382,6 +492,7 @@ def main():
                 line["end_to_end"]["standalone_process"] = {"error": str(e)[:200]}
         if not args.no_small_configs:
             line["configs"] = small_configs(S, local_rank, stream, torch)
+            line["cold_start"] = cold_start()
         if not args.no_single_pair:
             q, t = workloads.c4_pair(homolog=False)
             one = PairBatch.from_pairs([(q, t)])

@@ -14,7 +14,8 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_W
   NAME=$(echo $SET | cut -d' ' -f1)
   rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$NAME -- python3 bench.py $ARGS > $OUT/bench_pmc_$NAME.log 2>&1 || { echo "pmc $NAME failed"; tail -3 $OUT/bench_pmc_$NAME.log; }
 done
-python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+# (the JSON: what bench.py reads for roofline.traffic / valu / LDS -- copy it to profiles/hbm_traffic.json with the summary)
+python3 tools/summarize_prof.py $OUT --json $OUT/hbm_traffic.json --key ${TRAFFIC_KEY:-c5_100000_n1} > $OUT/summary.txt 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/trace $OUT/pmc_*
 cat $OUT/summary.txt
