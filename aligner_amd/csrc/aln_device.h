@@ -58,7 +58,8 @@ struct FillArgs {
     PairDesc *descs;
     const uint32_t *order;
     uint32_t n_pairs;
-    uint32_t *counter;        // work-queue head, zeroed before every launch
+    uint32_t *counter;        // zeroed before every launch: [0] work-queue head (generic kernels), [1] tail of the completion queue, [2] the walk
+                              // kernel's head, [4..5] the fast kernels' two-ended queue word (next_pair2)
     uint8_t *dirs;
     aln_pair_result *results;
     uint8_t *scratch;         // per-wave scratch base
@@ -87,6 +88,8 @@ struct FillArgs {
     uint32_t *coop;
     uint32_t n_descs;                // descriptors behind `descs` (a claimed strip names its pair by index)
     uint32_t coop_waves;             // fill waves = claim words = records (the claim words are padded to a multiple of 64)
+    uint32_t back_waves;             // fast kernels: 1 = the last third of the grid (the youngest wave of every SIMD of a full grid) takes its
+                                     // pairs from the back of the queue, the shortest first (next_pair2)
     uint32_t salt;                   // tag salt of this launch (aln_coop_tag)
     uint32_t coop_tail;              // first passes are opened for the pairs from this queue position on (the last ones taken; earlier
                                      // pairs finish while every wave still has pairs of its own to take)

@@ -385,8 +385,10 @@ struct Chunk {
     uint64_t seq_lo = 0, seq_span = 0;
 };
 
+// allow_overlap: the chunk has the device to itself (a single-chunk call, a staged batch).  many_chunks: one of more than four
+// chunks of a pipelined call.
 static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, const uint64_t *q_len, const uint64_t *t_off,
-                      const uint64_t *t_len, size_t first, size_t n, bool allow_overlap, Chunk &k)
+                      const uint64_t *t_len, size_t first, size_t n, bool allow_overlap, Chunk &k, bool many_chunks = false)
 {
     k.first = first; k.n = n;
     k.descs.assign(n, PairDesc{});
@@ -594,7 +596,9 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
             multi += (d.M > ALN_STRIP_ROWS || (c.semantics == ALN_CORE_LOCAL && c.p.del != c.p.ext && d.M > 64u && (uint64_t)d.N * d.M >= (1u << 18))) ? 1u : 0u;
         }
     }
-    k.coop = coop_on && k.n_small != 0 && multi != 0;
+    // (one of many chunks of a pipelined call: its tail hides behind the chunks after it, and sharing re-fills only cost -- measured on
+    // C5 through aln_align_batch, eight chunks: 51.2 ms without, 52.0 with; three chunks of the 12 500-pair shard: 10.3 without, 9.3 with)
+    k.coop = coop_on && k.n_small != 0 && multi != 0 && !many_chunks;
     if (k.coop) {
         const uint32_t resident = (uint32_t)ctx->cus * 3u;
         // (allow_overlap == false: a chunk of a pipelined call -- the chunks before and after it share the chip with this one, so its
@@ -761,7 +765,6 @@ static int slot_upload(Slot &s, const Call &c, const Chunk &k, const uint8_t *se
 static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipStream_t st, hipEvent_t *ev, uint32_t *fill_launches,
                        hipEvent_t fill_after = nullptr)
 {
-    (void)ctx;
     if (fill_launches) *fill_launches = 0;
     if (k.n == 0) return ALN_OK;
     if (k.n_small) HIPCHK(hipMemsetAsync(s.counter.p, 0, k.counter_bytes, st));     // the batch kernel's work queue
@@ -789,6 +792,10 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     fa.pwm_words = s.pwm_words.as<uint32_t>();
     fa.hmat = c.want_h ? s.hmat.p : nullptr; fa.blank = c.p.blank_code;
     fa.n_descs = (uint32_t)k.n;
+    // ALN_BACK_WAVES=1 (experiment, off): the youngest wave of every SIMD takes its pairs from the back of the queue (next_pair2).
+    // Measured on the 8-way shard of C5: fill 6.47-6.61 ms with it, 6.25 without -- the short pairs it moves to the slow waves are
+    // what filled the gaps at the end; r02 had seen the same with a queue in two segments.
+    { const char *e = getenv("ALN_BACK_WAVES"); fa.back_waves = (e && atoi(e) && k.grid == (uint32_t)ctx->cus * 3u && k.n_small >= 2ull * k.grid * 4u) ? 1u : 0u; }
     fa.coop = k.coop ? s.coop.as<uint32_t>() : nullptr; fa.coop_waves = k.grid * 4u; fa.coop_tail = k.coop_tail; fa.salt = s.salt;
     { const char *e = getenv("ALN_COOP_LINGER"); fa.coop_linger = e ? (uint32_t)atoi(e) : (k.coop_linger ? 1u : 0u); }
     { const char *e = getenv("ALN_COOP_DEBUG"); fa.coop_debug = e ? (uint32_t)atoi(e) : 0u; }
@@ -1097,7 +1104,7 @@ static void device_pipeline(DevCtx *dev, BatchJob &job)
         Chunk &k = plans[si];
         k = Chunk();
         // (walk waves beside the LAST chunk's own fill, as a staged batch has them, were measured: 53.7 ms against 52.0 without)
-        st = chunk_plan(dev, c, job.q_off, job.q_len, job.t_off, job.t_len, (*job.ranges)[ci].first, (*job.ranges)[ci].second, false, k);
+        st = chunk_plan(dev, c, job.q_off, job.q_len, job.t_off, job.t_len, (*job.ranges)[ci].first, (*job.ranges)[ci].second, false, k, nc > 4);
         if (st != ALN_OK) break;
         Slot &s = *slots[si];
         if ((st = slot_ensure(s, c, k, &job.need)) != ALN_OK) break;

@@ -1072,7 +1072,9 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
             // -- when that matters: while the queue still holds two pairs or more for every wave, the wave just fills it again by
             // itself (a shared re-fill takes other waves off their pairs and its smaller strips cost more instructions per cell:
             // 2 % of the C5 batch's fill when every re-fill was shared).  First passes: see FillArgs::coop_tail.
-            const bool share = coop_ok && (passes != 0 ? (coop_ld(a.counter) + 2u * cp.nw >= a.n_pairs || (a.coop_debug & 8u))
+            unsigned long long qw = 0;                   // the queue word: pairs taken from the front | from the back (next_pair2)
+            if (coop_ok && passes != 0) qw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.counter + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool share = coop_ok && (passes != 0 ? ((qw & 0xffffffffull) + (qw >> 32) + 2u * cp.nw >= a.n_pairs || (a.coop_debug & 8u))
                                                        : (qpos >= a.coop_tail && !(a.coop_debug & 1u)));
             Ru = (passes != 0 && share && SEM == ALN_CORE_LOCAL && !PWM && !(a.coop_debug & 4u)) ? aln_coop_uniform_r(M) : 0u;
             const uint32_t srows = Ru ? 64u * Ru : (uint32_t)ALN_STRIP_ROWS;
@@ -1256,6 +1258,21 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
 }  // namespace
 
 // ---------------------------------------------------------------- fill kernels: persistent waves over a work queue
+// The fast kernels' queue has two ends: {pairs taken from the front, pairs taken from the back} in ONE 64-bit word (counter[4..5]),
+// so that a take knows both counts at once: it is valid iff front + back < n before it, and then nobody else has its pair.  The
+// longest pairs sit at the front (LPT); the youngest wave of every SIMD -- which its two elders leave a quarter of the issue slots:
+// 0.39 GCUPS against 1.6 and 0.9 -- takes from the back, so that it is never the one that holds a 2-million-cell pair (its first
+// pair took it 5 of the 8-way shard's 6 ms) and the short pairs are out of the way before the queue runs dry.
+__device__ __forceinline__ bool next_pair2(const FillArgs &a, int lane, bool from_back, uint32_t &pair, uint32_t &idx)
+{
+    unsigned long long v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.counter + 4), from_back ? (1ull << 32) : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    if ((unsigned long long)f + b >= a.n_pairs) return false;
+    idx = from_back ? a.n_pairs - 1u - b : f;
+    pair = a.order[idx];
+    return true;
+}
 __device__ __forceinline__ bool next_pair(const FillArgs &a, int lane, uint32_t &pair, uint32_t &idx)
 {
     idx = 0;
@@ -1372,6 +1389,8 @@ void aln_fill_fast_kernel(FillArgs a)
     in.strip_rows = ALN_STRIP_ROWS; in.strip_q16 = 0; in.tag_base = 0;
     uint32_t pair = 0, qpos = 0, epoch = 0;
     bool dry = false;
+    // the third workgroup of every CU = the youngest wave of every SIMD (a full grid only; FillArgs::back_waves)
+    const bool from_back = a.back_waves != 0 && blockIdx.x * 3u >= gridDim.x * 2u;
     uint64_t idle_since = 0;
     for (;;) {
         // what next: strips other waves give away -- re-fills (urgent) before the next pair, first passes too once the queue is dry --
@@ -1380,7 +1399,7 @@ void aln_fill_fast_kernel(FillArgs a)
         uint32_t w = 0;
         if (COOP && cp.ctl) helper = coop_find(cp, !dry, in.lane, w, all_done, a.n_pairs);
         if (!helper) {
-            if (!dry && !next_pair(a, in.lane, pair, qpos)) {
+            if (!dry && !next_pair2(a, in.lane, from_back, pair, qpos)) {
                 dry = true;
                 if (COOP && cp.ctl) continue;            // first passes of other waves' pairs next
             }
