@@ -79,12 +79,13 @@ struct FillArgs {
     uint32_t pwm;             // 1: position-weight-matrix scoring: S[t[y-1]][x-1], the query codes are the column indices
     const uint32_t *pwm_words;// fast path: per column the four int8 scores 4*s - 2 of residues 0..3, packed
     uint32_t no_repair;       // 1: disable the localized strip-0 repair (testing: full re-fills only)
-    uint32_t cascade_rows;    // fast path: boundary rows in each wave's scratch: 1 = one row used in place; 2 = strip 0's bottom row
-                              // keeps a row of its own (hazard pairs: the localized repair compares against it)
+    uint32_t cascade_rows;    // fast path: boundary rows (8-byte granules) in each wave's scratch.  A strip never writes the row it reads,
+                              // so rows alternate: 2 = non-hazard semantics; 3 (ALN_CASCADE_ROWS) = hazard pairs, whose strip 0 keeps
+                              // its bottom row to itself (the localized repair compares against it) while strips 1.. alternate in the other two
     uint32_t zrow_bytes;      // bytes of the bottom-row record in each wave's scratch (bytes per column, or one direction word per block)
     void *hmat;               // optional: H dump, score type, (M+1)x(N+1) row-major per pair
     uint8_t blank;
-    // cooperative passes (fast kernels, see CoopRec): control words, hint rings and one record per fill wave; null = off
+    // cooperative passes (fast kernels, see CoopRec): control words, one claim word and one record per fill wave; null = off
     uint32_t *coop;
     uint32_t n_descs;                // descriptors behind `descs` (a claimed strip names its pair by index)
     uint32_t coop_waves;             // fill waves = claim words = records (the claim words are padded to a multiple of 64)
