@@ -217,6 +217,49 @@ static void pool_release(DevCtx *ctx, Slot **slots, int n)
 extern "C" const char *aln_last_error(void) { return g_err.c_str(); }
 extern "C" int aln_abi_version(void) { return ALN_ABI_VERSION; }
 
+// aln_create's warm-up: what a first call used to pay for (26-31 ms for a first 1000 x 1000 pair against 0.4 ms for the second;
+// aligner-cli aligns ONE pair per process, aligner-cli/main.rs:41-53).  Per device: the code objects are loaded (one per kernel
+// translation unit, aln_warm_*), and one synthetic 1000 x 1000 pair goes through aln_align_pair -- pool slot 0 with its stream,
+// events and staging, the buffers of the single-pair route at the size of the usual pair, the first launch of every kernel on
+// that route.  ALN_NO_WARMUP=1 leaves all of it to the first call as before.  A failure here is not an error of aln_create: the
+// first real call meets the same condition and reports it.
+extern "C" int aln_warm_fast_cl(void);
+extern "C" int aln_warm_fast_cl_solo(void);
+extern "C" int aln_warm_fast_rest(void);
+extern "C" int aln_warm_fast_rest_solo(void);
+extern "C" int aln_warm_generic(void);
+extern "C" int aln_warm_single(void);
+extern "C" int aln_warm_tb(void);
+static void warm_context(aln_ctx *c)
+{
+    if (getenv("ALN_NO_WARMUP")) return;
+    const uint32_t L = 1000;
+    std::vector<uint8_t> q(L), t(L);
+    uint32_t x = 12345u;
+    for (uint32_t i = 0; i < L; ++i) {
+        x = x * 1664525u + 1013904223u; q[i] = (uint8_t)((x >> 16) % 20u);
+        x = x * 1664525u + 1013904223u; t[i] = (i % 3u) ? q[i] : (uint8_t)((x >> 16) % 20u);
+    }
+    std::vector<double> mat(20 * 20);
+    for (int i = 0; i < 20; ++i) for (int j = 0; j < 20; ++j) mat[i * 20 + j] = i == j ? 5.0 : -2.0;
+    aln_params p;
+    memset(&p, 0, sizeof p);
+    p.semantics = ALN_CORE_LOCAL; p.del = 11.0; p.ext = 2.0;
+    p.matrix = mat.data(); p.rows = 20; p.cols = 20; p.row_stride = 20;
+    p.outputs = ALN_OUT_SCORE | ALN_OUT_TRACEBACK;
+    std::vector<uint8_t> qa(2 * L + 2), ta(2 * L + 2);
+    for (size_t d = 0; d < c->devs.size(); ++d) {
+        if (hipSetDevice(c->devs[d]->device) != hipSuccess) continue;
+        (void)aln_warm_single(); (void)aln_warm_tb(); (void)aln_warm_generic();
+        (void)aln_warm_fast_cl(); (void)aln_warm_fast_cl_solo(); (void)aln_warm_fast_rest(); (void)aln_warm_fast_rest_solo();
+        aln_pair_result r;
+        (void)aln_align_pair(c, &p, q.data(), L, t.data(), L, &r, qa.data(), ta.data(), nullptr, nullptr);   // devices in turn
+    }
+    c->turn.store(0);
+    (void)hipGetLastError();
+    g_err.clear();
+}
+
 extern "C" aln_ctx *aln_create_multi(int n_devices, const int *device_ids, int *status)
 {
     int st = ALN_OK;
@@ -254,6 +297,7 @@ extern "C" aln_ctx *aln_create_multi(int n_devices, const int *device_ids, int *
             c = nullptr;
         }
     }
+    if (c) warm_context(c);
     if (status) *status = st;
     return c;
 }

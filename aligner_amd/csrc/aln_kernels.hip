@@ -2423,6 +2423,38 @@ extern "C" void aln_launch_fill_fast_rest_solo(const FillArgs *a, uint32_t grid,
 }
 #endif
 #undef ALN_FAST_REST_LAUNCH
+// ---------------------------------------------------------------- code-object warm-up (aln_create)
+// Every translation unit is a code object of its own that the HIP runtime loads onto a device when the first kernel out of it is
+// launched (milliseconds each: a first call used to pay for them).  aln_create asks for the attributes of one kernel per unit,
+// which loads the unit without launching anything.
+#define ALN_WARM(fn, kernel)                                                                    \
+    extern "C" int fn(void)                                                                     \
+    {                                                                                           \
+        hipFuncAttributes attr;                                                                 \
+        return (int)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel));        \
+    }
+#if ALN_TU & ALN_PART_FAST_CL
+ALN_WARM(aln_warm_fast_cl, (&aln_fill_fast_kernel<ALN_CORE_LOCAL, false, true>))
+#endif
+#if ALN_TU & ALN_PART_FAST_CL_SOLO
+ALN_WARM(aln_warm_fast_cl_solo, (&aln_fill_fast_kernel<ALN_CORE_LOCAL, false, false>))
+#endif
+#if ALN_TU & ALN_PART_FAST_REST
+ALN_WARM(aln_warm_fast_rest, (&aln_fill_fast_kernel<ALN_CORE_GLOBAL, false, true>))
+#endif
+#if ALN_TU & ALN_PART_FAST_REST_SOLO
+ALN_WARM(aln_warm_fast_rest_solo, (&aln_fill_fast_kernel<ALN_CORE_GLOBAL, false, false>))
+#endif
+#if ALN_TU & ALN_PART_GENERIC
+ALN_WARM(aln_warm_generic, (&aln_validate_kernel))
+#endif
+#if ALN_TU & ALN_PART_SINGLE
+ALN_WARM(aln_warm_single, (&aln_single_init_kernel))
+#endif
+#if ALN_TU & ALN_PART_TB
+ALN_WARM(aln_warm_tb, (&aln_traceback_expand_kernel))
+#endif
+#undef ALN_WARM
 #if ALN_TU & ALN_PART_GENERIC
 extern "C" void aln_launch_fill_fast_cl(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_fill_fast_rest(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);

@@ -540,6 +540,22 @@ def main():
                 "what": "4 uniform-random + 4 homolog (10 % substitutions, 2 % indels) 10000 x ~10000 pairs, device fill + traceback",
                 "gcups_min": round(min(rates), 2), "gcups_median": round(sorted(rates)[len(rates) // 2], 2),
                 "locally_repaired": repaired, "second_full_pass": two_pass}
+            # pairs beyond the old ~29 400-column limit of the strip-pipelined route, through the blocking host call (upload, all
+            # kernels, download of the summary and both strings included); tests/test_gpu_parity.py checks them against the oracle
+            from aligner_amd import runtime
+            longp = {}
+            for N_, M_ in ((40000, 10000), (10000, 40000)):
+                qq = workloads.random_codes(4040 + N_, N_, 20)
+                tt = workloads.mutate(qq[:M_] if M_ <= N_ else np.concatenate([qq, workloads.random_codes(9 + N_, M_ - N_, 20)]), 1234 + N_, 20, 0.10, 0.02, out_len=M_)
+                runtime.align_pair(_ffi.CORE_LOCAL, qq, tt, 11, 2, S)
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rr = runtime.align_pair(_ffi.CORE_LOCAL, qq, tt, 11, 2, S)
+                    best = min(best, time.perf_counter() - t0)
+                longp["%dx%d" % (N_, M_)] = {"aln_align_pair_wall_ms": round(best * 1e3, 3), "gcups": round(N_ * M_ / best / 1e9, 2),
+                                            "strip_pipelined_route": bool(rr[0].flags & 2)}
+            line["single_pair"]["long_pairs"] = longp
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch, S, res)
     if rank == 0:
