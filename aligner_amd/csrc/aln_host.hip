@@ -1037,6 +1037,10 @@ static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_
     for (size_t i = 0; i < n; ++i) total += (double)(c.pwm ? c.cols : q_len[i]) * (double)t_len[i];
     // (several devices: the same bounds per device -- each takes about three chunks or more from the common queue)
     double target = std::min(1.6e10, std::max(5.0e9, total / (4.0 * (double)ndev)));
+    // The generic (f64 / off-fast-path) kernels take ~3 x as long per cell and have no cooperative passes: a chunk ends with its
+    // largest pairs alone on their waves for 10-30 ms, so what counts is pairs per wave, not overlap of the copies (r03, 20 000
+    // real-valued C5 pairs: four chunks 44.6 ms, one 40.7, resident 29.9).
+    if (!c.fast) target *= 3.0;
     if (const char *e = getenv("ALN_CHUNK_CELLS")) target = std::max(1.0, atof(e));
     if (total <= 1.5 * target) { out.emplace_back(0, n); return; }
     size_t first = 0;
@@ -1060,8 +1064,12 @@ extern "C" size_t aln_plan_chunks(const aln_params *params, const uint64_t *q_le
 {
     if (!params || (n_pairs && (!q_len || !t_len)) || n_devices < 1) return 0;
     Call c;
-    c.pwm = params->semantics == ALN_PWM_LOCAL;
-    c.cols = params->cols;
+    if (call_init(c, params, q_len, t_len, n_pairs, false) != ALN_OK) {      // lengths only (no matrix): planned as for the fast kernels
+        c = Call();
+        c.pwm = params->semantics == ALN_PWM_LOCAL;
+        c.cols = params->cols;
+        c.fast = true;
+    }
     std::vector<std::pair<size_t, size_t>> ranges;
     if (n_pairs) make_chunks(c, q_len, t_len, n_pairs, (size_t)n_devices, ranges);
     for (size_t i = 0; i < ranges.size() && i < cap; ++i) {
