@@ -97,6 +97,7 @@ struct FillArgs {
     uint32_t coop_linger;            // 1: waves that find the queue dry stay and take strips until every pair has finished
     uint32_t coop_debug;             // testing (ALN_COOP_DEBUG): bit 0 first passes are not opened; bit 1 no hints are posted (the owner
                                      // claims every strip of an open pass itself); bit 2 re-fills keep the skewed layout
+    uint32_t fair;                   // fast kernels: 0, or log2 of the time slice (10 ns ticks) in which the waves of a SIMD take turns at stepping down (FastStrip::fair_prio)
 };
 
 // ---- cooperative passes of the fast batch kernel

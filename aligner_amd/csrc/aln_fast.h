@@ -159,6 +159,8 @@ struct FastIn {
     // word and every end-cell candidate a strip hands on carries tag_base | strip, unique for (launch, owner's pass, strip): the
     // reader polls until it sees that tag, whoever ran the strip and whatever copies of older passes caches still hold
     uint32_t tag_base;
+    // batch kernels: 0, or (log2 of the time slice in 10 ns ticks) << 8 | the wave's slot in its SIMD (fair_prio)
+    uint32_t fair;
 };
 
 // The lane's running end-cell candidate (T form) + outcome flags; threaded through the strips by value.
@@ -283,11 +285,25 @@ struct FastStrip {
         flush_below(ksteps, kb_last >= 64u ? kb_last - 63u : 0u);
     }
 
+    // The SIMD's arbiter serves the two waves of highest priority -- oldest first among equals -- and the third only with what they
+    // leave: three VALU-bound waves run at 1.6 / 0.9 / 0.4 GCUPS by age.  A chain of strips is as slow as its slowest wave.  With
+    // `fair` set the three waves of a SIMD take turns at being the third: every 64 steps a wave looks at the 100 MHz clock and
+    // steps down to priority 0 during its own slice ((slice + slot) mod 3 == 0), priority 1 otherwise.  A wave never has to run to
+    // be promoted over the others (a starved wave would be late to do so -- rotating 0 / 1 / 2 left the youngest wave stale at
+    // 0); the slice (in.fair >> 8, log2 of 10 ns ticks) is about what a stepped-down wave needs for its next 64 steps.
+    __device__ __forceinline__ void fair_prio()
+    {
+        const uint32_t slice = (uint32_t)(wall_clock64() >> (in.fair >> 8));
+        if ((slice + (in.fair & 255u)) % 3u == 0u) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(1);
+    }
+
     template <bool MASKED>
     __device__ __forceinline__ void step(const uint32_t k)
     {
         if ((k & 63u) == 0) {                                   // wave-uniform: refill the 64-column input chunks
             const uint32_t xi = k + (uint32_t)lane;             // 0-based column
+            if (!SINGLE && in.fair) fair_prio();
             if (!SINGLE && !LAST && k >= 64u) flush_below(k, 0u);
             if (!FIRST && !SINGLE) inchunk = fetch_above(xi);
             if (SEM == ALN_CORE_LOCAL && FIRST && in.hazard) advchunk = (xi < N) ? in.advice[xi + 1] : 0u;

@@ -47,6 +47,7 @@ extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_
 extern "C" void aln_launch_validate(const uint8_t *seqs, PairDesc *descs, uint32_t n_pairs, uint32_t rows, uint32_t cols, int pwm,
                                     hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
+extern "C" void aln_launch_traceback_wave(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_overlap(const TraceArgs *a, uint32_t waves, hipStream_t s);
 extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s);
@@ -843,6 +844,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     fa.coop = k.coop ? s.coop.as<uint32_t>() : nullptr; fa.coop_waves = k.grid * 4u; fa.coop_tail = k.coop_tail; fa.salt = s.salt;
     { const char *e = getenv("ALN_COOP_LINGER"); fa.coop_linger = e ? (uint32_t)atoi(e) : (k.coop_linger ? 1u : 0u); }
     { const char *e = getenv("ALN_COOP_DEBUG"); fa.coop_debug = e ? (uint32_t)atoi(e) : 0u; }
+    { const char *e = getenv("ALN_FAIR"); fa.fair = e ? (uint32_t)atoi(e) : 0u; }
     if (fill_after) HIPCHK(hipStreamWaitEvent(st, fill_after, 0));
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     uint32_t launches = 0;
@@ -929,7 +931,15 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
         // every pair except those in the uniform-R layout (handled below); pairs the single-pair route hands to the strict-order
         // kernel (row-major layout) are walked by these two as well
         const bool batch_tb = k.n_small != 0 || c.semantics == ALN_CORE_LOCAL || !k.wg_pairs.empty();
-        if (batch_tb) aln_launch_traceback(&ta, st);
+        if (batch_tb) {
+            // few pairs: one WAVE per pair, its lanes fetching the direction quads ahead of the path (tb_walk_pair_wave: the walk of
+            // 256 pairs of 4200 x 4200 3.7 -> ~1 ms); many pairs: one lane per pair, 64 walks in flight per wave.  ALN_TB_WAVE=0 / 1
+            // forces one or the other.
+            bool wave_walk = k.n <= 2048;
+            if (const char *e = getenv("ALN_TB_WAVE")) wave_walk = atoi(e) != 0;
+            if (wave_walk) aln_launch_traceback_wave(&ta, st);
+            else aln_launch_traceback(&ta, st);
+        }
         for (size_t j = 0; j < k.single_pairs.size(); ++j) {
             const PairDesc &d = k.descs[k.single_pairs[j]];
             TraceSingleArgs tsa{};
@@ -1030,7 +1040,7 @@ static int slot_download(Slot &s, const Call &c, const Chunk &k, hipStream_t st,
 // Measured (profiles/r02_e2e_chunking.txt): C5 100 000 pairs (47.3 ms resident): 30 chunks 60 ms, 16 chunks 54 ms, 8 chunks 52 ms;
 // 25 000 pairs: 6 chunks 18.2 ms, 2-4 chunks 16.6-17.1, one chunk 21.1; 12 500 pairs: 7 chunks 15.6 ms, 3 chunks 9.7, one 10.7.
 static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_len, size_t n, size_t ndev,
-                        std::vector<std::pair<size_t, size_t>> &out)
+                        std::vector<std::pair<size_t, size_t>> &out, double waves = 3072.0)
 {
     out.clear();
     double total = 0;
@@ -1041,6 +1051,14 @@ static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_
     // largest pairs alone on their waves for 10-30 ms, so what counts is pairs per wave, not overlap of the copies (r03, 20 000
     // real-valued C5 pairs: four chunks 44.6 ms, one 40.7, resident 29.9).
     if (!c.fast) target *= 3.0;
+    // Large pairs: what a chunk needs is pairs, not cells -- two or more per resident wave, or the whole batch, so that either every
+    // wave has pairs of its own or the chunk is alone on the chip and its waves share the strips of a pair (cooperative passes are
+    // for a kernel that has the chip to itself).  r03, 1024 pairs of 4200 x 4200, score only: four chunks of 284 pairs 31 ms (one
+    // wave per pair, 9 strips one after the other), one chunk 11.2 ms; 2000 pairs 31 -> 17.3 ms; 512 pairs 15.7 -> 8.9 ms.  Large
+    // pairs carry few bytes per cell, so the copies that chunking would overlap are small; the cap keeps a chunk's packed directions
+    // at 16 GB (four slots).
+    // (pairs of C5's size -- 1.2e6 cells on average -- keep the bounds above: they were measured on them)
+    if (n && total / (double)n >= 3.0e6) target = std::max(target, std::min(6.4e10, 2.0 * waves * (total / (double)n)));
     if (const char *e = getenv("ALN_CHUNK_CELLS")) target = std::max(1.0, atof(e));
     if (total <= 1.5 * target) { out.emplace_back(0, n); return; }
     size_t first = 0;
@@ -1195,7 +1213,7 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
     if (st != ALN_OK) return st;
     if (n_pairs == 0) return ALN_OK;
     std::vector<std::pair<size_t, size_t>> ranges;
-    make_chunks(c, q_len, t_len, n_pairs, ctx->devs.size(), ranges);
+    make_chunks(c, q_len, t_len, n_pairs, ctx->devs.size(), ranges, 12.0 * (double)ctx->devs[0]->cus);
     const size_t nc = ranges.size();
 
     if (nc == 1) {                                   // one chunk: everything on the caller's thread, on the next device in turn

@@ -1387,6 +1387,7 @@ void aln_fill_fast_kernel(FillArgs a)
     in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.adv_any = false; in.store_dirs = true; in.pwm = false; in.pwm_words = nullptr; in.ck_mode = 0; in.last_flip = 0;
     in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0; in.ck_stop = 0; in.wt_dirs = false;
     in.strip_rows = ALN_STRIP_ROWS; in.strip_q16 = 0; in.tag_base = 0;
+    in.fair = a.fair ? (a.fair << 8) | (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u) : 0u;      // HW_ID[3:0]: the wave's slot in its SIMD
     uint32_t pair = 0, qpos = 0, epoch = 0;
     bool dry = false;
     // the third workgroup of every CU = the youngest wave of every SIMD (a full grid only; FillArgs::back_waves)
@@ -1589,6 +1590,7 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     if (a.test_drop != 0 && strip + 1 == a.test_drop) return;       // fault injection, see SingleArgs
     FastIn in;
     in.lane = threadIdx.x & 63;
+    in.fair = 0;
     in.N = desc.N; in.M = desc.M;
     in.q = qseq;
     in.t = a.seqs + desc.t_off;
@@ -1994,6 +1996,128 @@ extern "C" __global__ __launch_bounds__(64) void aln_traceback_kernel(TraceArgs 
     // latency-bound and light on issue slots: ahead of the fill waves (of the next chunk) it shares a SIMD with
     __builtin_amdgcn_s_setprio(3);
     tb_walk_pair(a, pair);
+}
+// ---------------------------------------------------------------- one WAVE per pair: the walk of a batch of few, long pairs
+// aln_traceback_kernel's walk waits for memory once per direction quad (a dependent 16-byte load every 4-8 steps, ~2 us when it comes
+// from HBM: 3.7 ms for the 8400-step paths of 256 pairs of 4200 x 4200 -- as long as their fill); with one pair per lane that is
+// the price of 64 walks in flight, with 256 pairs it is all there is.  Here a wave walks ONE pair and all its lanes fetch ahead:
+// wave lane j keeps, for lane j of the strip the path is in, the three quads around the step at which a purely diagonal path from
+// the current cell would enter that lane's rows -- one round of loads per strip (the path climbs through the lanes, 64 R rows), a new
+// round when gaps have carried it out of the three quads (8+ steps either way).  The state of the walk is wave-uniform: the step
+// runs on scalar registers, the quad it needs comes out of the window with v_readlane, the tags leave 64 at a time.
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <class T>
+__device__ __forceinline__ const T *uni_ptr(const T *p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<const T *>(((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v));
+}
+__device__ __forceinline__ StripView strip_view_uniform(const uint8_t *dirs, const PairDesc &d, uint32_t y)
+{
+    StripView v = strip_view(dirs, d, y);                    // (loads of the descriptor: the compiler cannot know they are uniform)
+    v.wbase = uni_ptr(v.wbase); v.y0 = uni32(v.y0); v.R = uni32(v.R); v.lgS = uni32(v.lgS);
+    return v;
+}
+__device__ __forceinline__ void tb_walk_pair_wave(const TraceArgs &a, const uint32_t pair)
+{
+    const PairDesc &d = a.descs[pair];
+    aln_pair_result &res = a.results[pair];
+    const uint32_t lane_id = threadIdx.x & 63u;
+    if (__builtin_amdgcn_readfirstlane(res.status) != ALN_OK) return;
+    const uint32_t layout = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.layout);
+    if ((layout & 0xffu) == ALN_LAYOUT_UNIFORM) return;      // large pairs of the single-pair route: aln_tb_single_* kernels
+    if (layout == ALN_LAYOUT_ROWMAJOR) {                     // strict-order fallback: rare, one lane
+        if (lane_id == 0) tb_walk_pair(a, pair);
+        return;
+    }
+    uint8_t *__restrict__ ops = a.tags + d.tag_off;
+    const bool global = (a.semantics == ALN_CORE_GLOBAL || a.semantics == ALN_LEGACY_GLOBAL);
+    const bool legacy = (a.semantics == ALN_LEGACY_GLOBAL || a.semantics == ALN_LEGACY_LOCAL);
+    const uint32_t N = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.N);
+    uint32_t cy = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.end_y), cx = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.end_x);
+    if (legacy) { cy -= 1; cx -= 1; }
+    uint32_t len = 0;
+    uint32_t tagv = 0;                                       // lane i: tag number (len & ~63) + i
+    if (cy != 0 && cx != 0) {
+        StripView sv = strip_view_uniform(a.dirs, d, cy);
+        int iy = (int)(cy - 1 - sv.y0), cxm = (int)cx - 1;
+        uint32_t R = sv.R, rinv = (65535u + R) / R, lgS = sv.lgS, qsh = lgS + 2u, bmask = (1u << lgS) - 1u;
+        const uint4 *wq = reinterpret_cast<const uint4 *>(sv.wbase);
+        const uint32_t Nm1 = N - 1u;
+        uint32_t nq = ((N + 62u) >> qsh) + 1u;              // quad rows of a strip (steps 0 .. N + 62)
+        uint4 wa = make_uint4(0, 0, 0, 0), wb = wa, wc = wa; // quad rows qrow + 1, qrow, qrow - 1 of strip lane `lane_id`
+        uint32_t qrow = 0;
+        bool have = false;                                   // the window belongs to the current strip
+        uint32_t cur_lane = 0xffffffffu, cur_q = 0xffffffffu;
+        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;             // the current quad (uniform)
+        for (;;) {
+            if ((iy | cxm) < 0) {                            // above the strip, or a border
+                cy = (uint32_t)(iy + 1) + sv.y0; cx = (uint32_t)(cxm + 1);
+                if (cy == 0 || cx == 0) break;
+                sv = strip_view_uniform(a.dirs, d, cy);
+                iy = (int)(cy - 1 - sv.y0);
+                R = sv.R; rinv = (65535u + R) / R; lgS = sv.lgS; qsh = lgS + 2u; bmask = (1u << lgS) - 1u;
+                wq = reinterpret_cast<const uint4 *>(sv.wbase);
+                nq = ((N + 62u) >> qsh) + 1u;
+                have = false; cur_lane = 0xffffffffu;
+            }
+            const uint32_t lane = ((uint32_t)iy * rinv) >> 16, r = (uint32_t)iy - lane * R;
+            const uint32_t k = (uint32_t)cxm + lane;
+            const uint32_t qr = k >> qsh;
+            if (lane != cur_lane || qr != cur_q) {           // (uniform) another quad: out of the window
+                uint32_t dq = (uint32_t)__builtin_amdgcn_readlane((int)qrow, (int)lane) + 1u - qr;      // 0 / 1 / 2: wa / wb / wc
+                if (!have || dq > 2u) {
+                    // fetch ahead from here: strip lane j <= lane is entered after t = iy - (j R + R - 1) diagonal steps, at step
+                    // k_j = (cxm - t) + j; its R rows take the path down to k_j - (R - 1): the middle quad holds k_j - R / 2
+                    const int t = iy - (int)(lane_id * R + R - 1u);
+                    const int kj = (cxm - (t > 0 ? t : 0)) + (int)lane_id - (int)(R >> 1);
+                    qrow = (uint32_t)(kj > 0 ? kj : 0) >> qsh;
+                    if (lane_id == lane) qrow = qr;          // (the lane the path is in: exactly the quad of this step)
+                    const bool on = lane_id <= lane;
+                    wa = wb = wc = make_uint4(0, 0, 0, 0);
+                    if (on && qrow + 1u < nq) wa = wq[((size_t)(qrow + 1u) << 6) + lane_id];
+                    if (on && qrow < nq) wb = wq[((size_t)qrow << 6) + lane_id];
+                    if (on && qrow >= 1u) wc = wq[((size_t)(qrow - 1u) << 6) + lane_id];
+                    have = true;
+                    dq = 1u;
+                }
+                const int li = (int)lane;
+                if (dq == 0u) { q0 = __builtin_amdgcn_readlane((int)wa.x, li); q1 = __builtin_amdgcn_readlane((int)wa.y, li); q2 = __builtin_amdgcn_readlane((int)wa.z, li); q3 = __builtin_amdgcn_readlane((int)wa.w, li); }
+                else if (dq == 1u) { q0 = __builtin_amdgcn_readlane((int)wb.x, li); q1 = __builtin_amdgcn_readlane((int)wb.y, li); q2 = __builtin_amdgcn_readlane((int)wb.z, li); q3 = __builtin_amdgcn_readlane((int)wb.w, li); }
+                else { q0 = __builtin_amdgcn_readlane((int)wc.x, li); q1 = __builtin_amdgcn_readlane((int)wc.y, li); q2 = __builtin_amdgcn_readlane((int)wc.z, li); q3 = __builtin_amdgcn_readlane((int)wc.w, li); }
+                cur_lane = lane; cur_q = qr;
+            }
+            const uint32_t lend = lane + Nm1;
+            const uint32_t m = min(k | bmask, lend) - k;
+            const uint32_t j = (k >> lgS) & 3u;
+            const uint64_t half = (j & 2u) ? (((uint64_t)q3 << 32) | q2) : (((uint64_t)q1 << 32) | q0);
+            const uint32_t tag = (uint32_t)(half >> (32u * (j & 1u) + 32u - 2u * R * (m + 1u) + 2u * r)) & 3u;
+            if (tag == 3u) {                                 // Beginning
+                cy = (uint32_t)(iy + 1) + sv.y0; cx = (uint32_t)(cxm + 1);
+                break;
+            }
+            tagv = (lane_id == (len & 63u)) ? tag : tagv;     // (v_writelane takes one scalar operand only: tag and lane would be two)
+            ++len;
+            if ((len & 63u) == 0u) ops[len - 64u + lane_id] = (uint8_t)tagv;
+            iy -= (tag != 1u); cxm -= (tag != 2u);           // 0 Diagonal, 1 Left, 2 Top
+        }
+    }
+    if (lane_id < (len & 63u)) ops[(len & ~63u) + lane_id] = (uint8_t)tagv;
+    if (global) {                                            // borders: D[0][x] = Left, D[y][0] = Top (simple/mod.rs:59-67)
+        if (cy == 0 && cx != 0) { for (uint32_t i = lane_id; i < cx; i += 64u) ops[len + i] = 1; len += cx; cx = 0; }
+        else if (cx == 0 && cy != 0) { for (uint32_t i = lane_id; i < cy; i += 64u) ops[len + i] = 2; len += cy; cy = 0; }
+    }
+    if (lane_id == 0) {
+        res.start_y = cy; res.start_x = cx;
+        res.aln_len = len + (a.pwm ? 0u : 1u);               // + the duplicated seed pair (none for the PWM aligner)
+    }
+}
+extern "C" __global__ __launch_bounds__(256) void aln_traceback_wave_kernel(TraceArgs a)
+{
+    const uint32_t pair = uni32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (pair >= a.n_pairs) return;
+    if (a.walked && uni32(a.walked[pair]) == a.epoch) return;
+    tb_walk_pair_wave(a, pair);
 }
 // The walks are latency-bound and the fill is issue-bound: this kernel runs BESIDE the fill kernel (second stream; the host
 // leaves a few workgroup slots free for it) and walks the pairs in the order the fill finishes them: persistent waves, each
@@ -2606,6 +2730,10 @@ extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
 {
     const uint32_t grid = (a->n_pairs + 63) / 64;
     hipLaunchKernelGGL(aln_traceback_kernel, dim3(grid), dim3(64), 0, s, *a);
+}
+extern "C" void aln_launch_traceback_wave(const TraceArgs *a, hipStream_t s)
+{
+    hipLaunchKernelGGL(aln_traceback_wave_kernel, dim3((a->n_pairs + 3) / 4), dim3(256), 0, s, *a);
 }
 extern "C" void aln_launch_traceback_overlap(const TraceArgs *a, uint32_t waves, hipStream_t s)
 {
