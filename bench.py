@@ -237,23 +237,24 @@ def small_configs(S, local_rank, stream, torch):
                             "scores_equal_oracle": bool(all(float(resp[i]["f"]) == refp[i].f for i in range(len(pb))))}
     # batches of LARGE pairs (r02: every pair of >= 2^24 cells took the single-pair route, one after the other): 256 pairs of
     # 4200 x 4200 through aln_align_batch, host buffers in and out -- the batch kernel shares the strips of a pair between waves
-    bb = workloads.c5_batch(n_pairs=256, lo=4200, hi=4200)
     pbig, keep_b = runtime.make_params(_ffi.CORE_LOCAL, 11, 2, S, outputs=_ffi.OUT_SCORE | _ffi.OUT_TRACEBACK)
-    resb = np.zeros(len(bb), dtype=RESULT_DTYPE)
-    tbo, tbt = bb.tb_layout()
-    tbb = np.zeros(max(tbt, 1), dtype=np.uint8)
-    tsb = []
-    for _ in range(4):
-        t0 = time.perf_counter()
-        st = lib.aln_align_batch(ctxp, C.byref(pbig), bb.seqs.ctypes.data, bb.q_off.ctypes.data, bb.q_len.ctypes.data, bb.t_off.ctypes.data,
-                                 bb.t_len.ctypes.data, len(bb), resb.ctypes.data, tbb.ctypes.data, tbo.ctypes.data)
-        tsb.append(time.perf_counter() - t0)
-        runtime.raise_for_status(st, "aln_align_batch")
-    dtb = min(tsb[1:])
-    out["large_pairs_batch"] = {"workload": "256 protein pairs of 4200 x 4200 (1.8e7 cells each), core local, BLOSUM62 11/2, summaries + both strings, "
-                                            "host buffers in and out",
-                                "ms": round(dtb * 1e3, 3), "gcups": round(bb.cells / dtb / 1e9, 2),
-                                "pairs_on_single_pair_route": int(((resb["flags"] & 2) != 0).sum()), "pairs_ok": int((resb["status"] == 0).sum())}
+    for key, npairs in (("large_pairs_batch", 256), ("large_pairs_batch_1024", 1024)):
+        bb = workloads.c5_batch(n_pairs=npairs, lo=4200, hi=4200)
+        resb = np.zeros(len(bb), dtype=RESULT_DTYPE)
+        tbo, tbt = bb.tb_layout()
+        tbb = np.zeros(max(tbt, 1), dtype=np.uint8)
+        tsb = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            st = lib.aln_align_batch(ctxp, C.byref(pbig), bb.seqs.ctypes.data, bb.q_off.ctypes.data, bb.q_len.ctypes.data, bb.t_off.ctypes.data,
+                                     bb.t_len.ctypes.data, len(bb), resb.ctypes.data, tbb.ctypes.data, tbo.ctypes.data)
+            tsb.append(time.perf_counter() - t0)
+            runtime.raise_for_status(st, "aln_align_batch")
+        dtb = min(tsb[1:])
+        out[key] = {"workload": "%d protein pairs of 4200 x 4200 (1.8e7 cells each), core local, BLOSUM62 11/2, summaries + both strings, "
+                                "host buffers in and out" % npairs,
+                    "ms": round(dtb * 1e3, 3), "gcups": round(bb.cells / dtb / 1e9, 2),
+                    "pairs_on_single_pair_route": int(((resb["flags"] & 2) != 0).sum()), "pairs_ok": int((resb["status"] == 0).sum())}
     # a batch with a real-valued matrix (f64 kernels): the first 20000 C5 pairs, BLOSUM62 x 0.5, 11.5 / 2.25, host to host
     from aligner_amd.batch import align_batch
     bf = workloads.c5_batch(20000)

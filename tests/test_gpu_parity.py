@@ -409,6 +409,52 @@ def _same_batch_results(a, b, n, strings_every=1):
         assert (qa == qb).all() and (ta == tb).all(), i
 
 
+@pytest.mark.parametrize("sem", [_ffi.CORE_LOCAL, _ffi.CORE_GLOBAL, _ffi.LEGACY_GLOBAL, _ffi.LEGACY_LOCAL])
+def test_wave_walk_equals_lane_walk_and_oracle(orc, blosum62, monkeypatch, sem):
+    """Batches of up to 2048 pairs are walked by one WAVE per pair, whose lanes fetch the direction quads ahead of the path along
+    the diagonal (tb_walk_pair_wave); larger ones by one lane per pair.  Same strings either way, and the oracle's: pairs whose
+    paths run through long gaps (inserted / deleted blocks of 5..400 residues carry the path out of the fetched window, so the
+    window is re-centred many times), paths that cross several strips, short last strips (every R), end cells on the borders
+    (global semantics: the border runs are written by all lanes), pairs of one row or one column."""
+    rng = np.random.default_rng(77 + sem)
+    pairs = []
+    for i in range(160):
+        N = int(rng.integers(1, 2600)) if i % 7 else int(rng.integers(1, 5))
+        q = rng.integers(0, 20, N).astype(np.uint8)
+        t = q.copy()
+        for _ in range(int(rng.integers(0, 6))):                 # block indels
+            L = int(rng.integers(5, 400)); pos = int(rng.integers(0, len(t) + 1))
+            if rng.random() < 0.5:
+                t = np.concatenate([t[:pos], rng.integers(0, 20, L).astype(np.uint8), t[pos:]])
+            else:
+                t = np.concatenate([t[:pos], t[pos + L:]])
+        if len(t) == 0 or i % 11 == 0:
+            t = rng.integers(0, 20, int(rng.integers(1, 1500))).astype(np.uint8)
+        sub = rng.random(len(t)) < 0.05
+        t = np.where(sub, rng.integers(0, 20, len(t)), t).astype(np.uint8)
+        pairs.append((q, t))
+    pb = PairBatch.from_pairs(pairs)
+    dele, ext = (11, 2) if sem in (_ffi.CORE_LOCAL, _ffi.CORE_GLOBAL) else (4, 4)
+    monkeypatch.setenv("ALN_TB_WAVE", "1")
+    wave = align_batch(pb, sem, dele, ext, blosum62)
+    monkeypatch.setenv("ALN_TB_WAVE", "0")
+    lanew = align_batch(pb, sem, dele, ext, blosum62)
+    monkeypatch.delenv("ALN_TB_WAVE")
+    _same_batch_results(wave, lanew, len(pb))
+    ref, tb, tb_off = orc.align_batch(sem, pb.seqs, pb.q_off, pb.q_len, pb.t_off, pb.t_len, dele, ext, blosum62, 16)
+    for i in range(len(pb)):
+        r, g = ref[i], wave.results[i]
+        assert int(g["status"]) == r.status, i
+        if r.status:
+            continue
+        assert (g["score"], g["f"], g["end_y"], g["end_x"], g["start_y"], g["start_x"], g["aln_len"]) == \
+            (r.score, r.f, r.end_y, r.end_x, r.start_y, r.start_x, r.aln_len), i
+        cap = int(pb.q_len[i] + pb.t_len[i]) + 2
+        o = int(tb_off[i])
+        qa, ta = wave.aligned(i)
+        assert (qa == tb[o:o + r.aln_len]).all() and (ta == tb[o + cap:o + cap + r.aln_len]).all(), i
+
+
 def test_batch_of_large_pairs_shares_the_strips_of_a_pair(orc, blosum62, monkeypatch):
     """256 pairs of 4200 x 4200 (1.8e7 cells each: above the old 2^24-cell line every one of them took the single-pair route, one
     after the other).  The batch kernel now takes them -- fewer pairs than resident waves, so the waves without a pair claim strips

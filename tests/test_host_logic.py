@@ -276,3 +276,12 @@ def test_in_library_chunking_for_any_device_count():
     # a small batch is one chunk; nothing at all is no chunk
     assert lib.aln_plan_chunks(C.byref(p), ql.ctypes.data, tl.ctypes.data, 500, 8, None, None, 0) == 1
     assert lib.aln_plan_chunks(C.byref(p), ql.ctypes.data, tl.ctypes.data, 0, 1, None, None, 0) == 0
+    # large pairs: a chunk holds two pairs per resident wave (6144) or the whole batch -- 1024 and 3072 pairs of 4200 x 4200 are one
+    # chunk each (r02's bounds cut them into 4 and 11 chunks of 284 pairs: one wave per pair, nine strips one after the other);
+    # 10 000 of them are cut at the 6.4e10-cell cap
+    big = np.full(10000, 4200, np.uint64)
+    assert lib.aln_plan_chunks(C.byref(p), big.ctypes.data, big.ctypes.data, 1024, 1, None, None, 0) == 1
+    assert lib.aln_plan_chunks(C.byref(p), big.ctypes.data, big.ctypes.data, 3072, 1, None, None, 0) == 1
+    first, count = np.zeros(64, np.uint64), np.zeros(64, np.uint64)
+    n = lib.aln_plan_chunks(C.byref(p), big.ctypes.data, big.ctypes.data, 10000, 1, first.ctypes.data, count.ctypes.data, 64)
+    assert n == 3 and int(count[:n].sum()) == 10000 and int(count[0]) * 4200 * 4200 <= 6.4e10 * 1.01
