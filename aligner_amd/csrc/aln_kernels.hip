@@ -143,8 +143,8 @@ __device__ __forceinline__ uint32_t cell_tag_f64(double top, double left, double
         "v_max_f64 %3, %3, %2\n\t"
         "v_add_f64 %4, %3, -%0\n\t"
         "v_add_f64 %5, %3, -%1"
-        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(m), "=&v"(da), "=&v"(db)
-        : "v"(top), "v"(left), "v"(diag), "v"(negp), "v"(s));
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=v"(m), "=v"(da), "=v"(db)      // m, da, db are written after the last read of an input: they may
+        : "v"(top), "v"(left), "v"(diag), "v"(negp), "v"(s));             // take an input's registers (the new H lands where the old one was)
     uint32_t tag = (db < DBL_EPSILON) ? 1u : 0u;
     tag = (da < DBL_EPSILON) ? 2u : tag;                              // Top > Left > Diagonal
     zero = (m == 0.0);
