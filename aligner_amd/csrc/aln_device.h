@@ -97,6 +97,9 @@ struct FillArgs {
     uint32_t coop_linger;            // 1: waves that find the queue dry stay and take strips until every pair has finished
     uint32_t coop_debug;             // testing (ALN_COOP_DEBUG): bit 0 first passes are not opened; bit 1 no hints are posted (the owner
                                      // claims every strip of an open pass itself); bit 2 re-fills keep the skewed layout
+    uint32_t claim;                  // fast kernels without cooperative passes: queue positions a wave takes per atomic (1..4): batches of
+                                     // many equal short pairs keep their waves in step, and 3000 waves at one counter within a microsecond
+                                     // wait for each other (C3: 14 of the 47 us a wave spends per pair lay between two pairs)
     uint32_t fair;                   // fast kernels: 0, or log2 of the time slice (10 ns ticks) in which the waves of a SIMD take turns at stepping down (FastStrip::fair_prio)
 };
 

@@ -33,6 +33,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -845,6 +846,16 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     { const char *e = getenv("ALN_COOP_LINGER"); fa.coop_linger = e ? (uint32_t)atoi(e) : (k.coop_linger ? 1u : 0u); }
     { const char *e = getenv("ALN_COOP_DEBUG"); fa.coop_debug = e ? (uint32_t)atoi(e) : 0u; }
     { const char *e = getenv("ALN_FAIR"); fa.fair = e ? (uint32_t)atoi(e) : 0u; }
+    // runs of queue positions per atomic: only where pairs are many, short and alike (one strip, <= 2^18 cells), nothing is shared
+    // and the queue is not two-ended; about 1.6 runs per wave or more, so that the last round stays as even as with single pairs
+    fa.claim = 1;
+    if (c.fast && !k.coop && !fa.back_waves && k.max_cells <= (1ull << 18) && k.n_small != 0) {
+        const double per_wave = (double)k.n_small / ((double)std::min(k.grid, (uint32_t)ctx->cus * 3u) * 4.0);     // resident waves
+        // (measured: C3, 3.3 pairs per wave: runs of 2 fill 0.232 -> 0.204 ms, runs of 3 / 4 0.218 / 0.222 -- the last round gets uneven;
+        // 100 000 PWM windows, 32 per wave: runs of 4 cost 4 % -- with many pairs per wave the waves drift apart by themselves)
+        fa.claim = (per_wave >= 3.2 && per_wave < 12.0) ? 2u : 1u;
+    }
+    if (const char *e = getenv("ALN_CLAIM")) fa.claim = (uint32_t)std::max(1, std::min(8, atoi(e)));
     if (fill_after) HIPCHK(hipStreamWaitEvent(st, fill_after, 0));
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     uint32_t launches = 0;
@@ -1224,11 +1235,25 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
         struct Release { DevCtx *c; Slot **s; ~Release() { pool_release(c, s, 1); } } rel{dev, sl};
         Chunk k;
         Slot &s = *sl[0];
+        // ALN_TRACE_CALL=1: where the wall clock of a one-chunk call goes (stderr)
+        const bool trace = getenv("ALN_TRACE_CALL") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t0 = now();
         if ((st = chunk_plan(dev, c, q_off, q_len, t_off, t_len, 0, n_pairs, true, k)) != ALN_OK) return st;
+        const auto t1 = now();
         if ((st = slot_ensure(s, c, k)) != ALN_OK) return st;
+        const auto t2 = now();
         if ((st = slot_upload(s, c, k, seqs, q_off, q_len, t_off, t_len, s.stream)) != ALN_OK) return st;
+        const auto t3 = now();
         if ((st = slot_launch(dev, s, c, k, s.stream, nullptr, nullptr)) != ALN_OK) { (void)hipStreamSynchronize(s.stream); return st; }
-        return slot_download(s, c, k, s.stream, results, tb_buf, tb_off);
+        const auto t4 = now();
+        if (trace) (void)hipStreamSynchronize(s.stream);
+        const auto t5 = now();
+        st = slot_download(s, c, k, s.stream, results, tb_buf, tb_off);
+        if (trace) fprintf(stderr, "aln_align_batch (one chunk, %zu pairs): plan %.3f ensure %.3f upload %.3f launch %.3f kernels %.3f download %.3f ms\n",
+                           n_pairs, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, now()));
+        return st;
     }
 
     BatchJob job;

@@ -1393,6 +1393,7 @@ void aln_fill_fast_kernel(FillArgs a)
     // the third workgroup of every CU = the youngest wave of every SIMD (a full grid only; FillArgs::back_waves)
     const bool from_back = a.back_waves != 0 && blockIdx.x * 3u >= gridDim.x * 2u;
     uint64_t idle_since = 0;
+    uint32_t run_left = 0, run_pos = 0;                      // FillArgs::claim > 1: the rest of the run of queue positions this wave took
     for (;;) {
         // what next: strips other waves give away -- re-fills (urgent) before the next pair, first passes too once the queue is dry --
         // else the next pair of the queue, else (the queue is dry) wait for either
@@ -1400,7 +1401,17 @@ void aln_fill_fast_kernel(FillArgs a)
         uint32_t w = 0;
         if (COOP && cp.ctl) helper = coop_find(cp, !dry, in.lane, w, all_done, a.n_pairs);
         if (!helper) {
-            if (!dry && !next_pair2(a, in.lane, from_back, pair, qpos)) {
+            bool got = false;
+            if (!COOP && a.claim > 1u) {
+                if (!dry && run_left == 0u) {
+                    unsigned long long v = 0;
+                    if (in.lane == 0) v = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.counter + 4), (unsigned long long)a.claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+                    if (f < a.n_pairs) { run_pos = f; run_left = min(a.claim, a.n_pairs - f); }
+                }
+                if (run_left != 0u) { qpos = run_pos++; --run_left; pair = a.order[qpos]; got = true; }
+            } else if (!dry) got = next_pair2(a, in.lane, from_back, pair, qpos);
+            if (!dry && !got) {
                 dry = true;
                 if (COOP && cp.ctl) continue;            // first passes of other waves' pairs next
             }

@@ -409,6 +409,42 @@ def _same_batch_results(a, b, n, strings_every=1):
         assert (qa == qb).all() and (ta == tb).all(), i
 
 
+@pytest.mark.parametrize("claim", ["2", "3", "4"])
+def test_waves_take_runs_of_queue_positions(orc, monkeypatch, claim):
+    """Batches of many short, alike pairs (read pairs) let a wave take a run of queue positions per atomic (FillArgs::claim; C3 takes
+    runs of 2 by itself).  Forced to 2 / 3 / 4 on a batch whose size is no multiple of any of them, with pairs of every length
+    20..220 and two pairs the reference would panic on inside runs: every pair once, every result the oracle's."""
+    rng = np.random.default_rng(5 + int(claim))
+    S = nucleotide_matrix()
+    pairs = []
+    for i in range(7001):
+        N, M = int(rng.integers(20, 221)), int(rng.integers(20, 221))
+        q = rng.integers(0, 4, N).astype(np.uint8)
+        t = rng.integers(0, 4, M).astype(np.uint8)
+        L = min(N, M) // 2
+        t[:L] = q[:L]
+        pairs.append((q, t))
+    pairs[1234] = (pairs[1234][0], np.full(50, 9, np.uint8))              # a code outside the matrix
+    pairs[7000] = (np.full(33, 200, np.uint8), pairs[7000][1])
+    pb = PairBatch.from_pairs(pairs)
+    monkeypatch.setenv("ALN_CLAIM", claim)
+    got = align_batch(pb, _ffi.CORE_GLOBAL, 10, 1, S)
+    monkeypatch.delenv("ALN_CLAIM")
+    ref, tb, tb_off = orc.align_batch(_ffi.CORE_GLOBAL, pb.seqs, pb.q_off, pb.q_len, pb.t_off, pb.t_len, 10, 1, S, 16)
+    assert int(got.results["status"][1234]) == ref[1234].status != 0 and int(got.results["status"][7000]) == ref[7000].status != 0
+    for i in range(len(pb)):
+        r, g = ref[i], got.results[i]
+        assert int(g["status"]) == r.status, i
+        if r.status:
+            continue
+        assert (g["score"], g["f"], g["aln_len"]) == (r.score, r.f, r.aln_len), i
+        if i % 7 == 0:
+            cap = int(pb.q_len[i] + pb.t_len[i]) + 2
+            o = int(tb_off[i])
+            qa, ta = got.aligned(i)
+            assert (qa == tb[o:o + r.aln_len]).all() and (ta == tb[o + cap:o + cap + r.aln_len]).all(), i
+
+
 @pytest.mark.parametrize("sem", [_ffi.CORE_LOCAL, _ffi.CORE_GLOBAL, _ffi.LEGACY_GLOBAL, _ffi.LEGACY_LOCAL])
 def test_wave_walk_equals_lane_walk_and_oracle(orc, blosum62, monkeypatch, sem):
     """Batches of up to 2048 pairs are walked by one WAVE per pair, whose lanes fetch the direction quads ahead of the path along
