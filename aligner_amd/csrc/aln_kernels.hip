@@ -2048,7 +2048,7 @@ __device__ __forceinline__ void tb_walk_pair_wave(const TraceArgs &a, const uint
     uint32_t cy = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.end_y), cx = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.end_x);
     if (legacy) { cy -= 1; cx -= 1; }
     uint32_t len = 0;
-    uint32_t tagv = 0;                                       // lane i: tag number (len & ~63) + i
+    uint32_t tagv = 0;                                       // lane i: the tag of i steps ago
     if (cy != 0 && cx != 0) {
         StripView sv = strip_view_uniform(a.dirs, d, cy);
         int iy = (int)(cy - 1 - sv.y0), cxm = (int)cx - 1;
@@ -2097,6 +2097,7 @@ __device__ __forceinline__ void tb_walk_pair_wave(const TraceArgs &a, const uint
                 else if (dq == 1u) { q0 = __builtin_amdgcn_readlane((int)wb.x, li); q1 = __builtin_amdgcn_readlane((int)wb.y, li); q2 = __builtin_amdgcn_readlane((int)wb.z, li); q3 = __builtin_amdgcn_readlane((int)wb.w, li); }
                 else { q0 = __builtin_amdgcn_readlane((int)wc.x, li); q1 = __builtin_amdgcn_readlane((int)wc.y, li); q2 = __builtin_amdgcn_readlane((int)wc.z, li); q3 = __builtin_amdgcn_readlane((int)wc.w, li); }
                 cur_lane = lane; cur_q = qr;
+                asm volatile("" : "+s"(cur_lane), "+s"(cur_q));      // (scalars: say so)
             }
             const uint32_t lend = lane + Nm1;
             const uint32_t m = min(k | bmask, lend) - k;
@@ -2107,13 +2108,15 @@ __device__ __forceinline__ void tb_walk_pair_wave(const TraceArgs &a, const uint
                 cy = (uint32_t)(iy + 1) + sv.y0; cx = (uint32_t)(cxm + 1);
                 break;
             }
-            tagv = (lane_id == (len & 63u)) ? tag : tagv;     // (v_writelane takes one scalar operand only: tag and lane would be two)
+            // the tags enter a lane shift register at lane 0 (one DPP move per step; the step counter stays out of vector code, or
+            // the compiler moves the whole walk state there): after 64 steps lane i holds the tag of step 63 - i of the group
+            tagv = (uint32_t)__builtin_amdgcn_update_dpp((int)tag, (int)tagv, 0x138, 0xf, 0xf, false);
             ++len;
-            if ((len & 63u) == 0u) ops[len - 64u + lane_id] = (uint8_t)tagv;
+            if ((len & 63u) == 0u) ops[len - 1u - lane_id] = (uint8_t)tagv;
             iy -= (tag != 1u); cxm -= (tag != 2u);           // 0 Diagonal, 1 Left, 2 Top
         }
     }
-    if (lane_id < (len & 63u)) ops[(len & ~63u) + lane_id] = (uint8_t)tagv;
+    if (lane_id < (len & 63u)) ops[len - 1u - lane_id] = (uint8_t)tagv;       // the last, partial group: lane i holds tag len - 1 - i
     if (global) {                                            // borders: D[0][x] = Left, D[y][0] = Top (simple/mod.rs:59-67)
         if (cy == 0 && cx != 0) { for (uint32_t i = lane_id; i < cx; i += 64u) ops[len + i] = 1; len += cx; cx = 0; }
         else if (cx == 0 && cy != 0) { for (uint32_t i = lane_id; i < cy; i += 64u) ops[len + i] = 2; len += cy; cy = 0; }
