@@ -429,6 +429,16 @@ struct Chunk {
     // sequences: either one contiguous span of the caller's buffer, or gathered pair by pair into pinned staging
     bool seq_direct = true;
     uint64_t seq_lo = 0, seq_span = 0;
+    // a plan that is planned again keeps its arrays (6.4 MB of descriptors for 100 000 pairs: allocating and faulting them in afresh
+    // was 1 of the 2 ms the plan of a 100 000-window call took)
+    void reset()
+    {
+        std::vector<PairDesc> d = std::move(descs);
+        std::vector<uint32_t> o = std::move(order), sp = std::move(single_pairs), sr = std::move(single_r), wp = std::move(wg_pairs), wr = std::move(wg_r);
+        *this = Chunk();
+        d.clear(); o.clear(); sp.clear(); sr.clear(); wp.clear(); wr.clear();
+        descs = std::move(d); order = std::move(o); single_pairs = std::move(sp); single_r = std::move(sr); wg_pairs = std::move(wp); wg_r = std::move(wr);
+    }
 };
 
 // allow_overlap: the chunk has the device to itself (a single-chunk call, a staged batch).  many_chunks: one of more than four
@@ -596,7 +606,9 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
             key[j] = ((~pc & ((1ull << 40) - 1)) << 24) | k.order[j];
         }
         if (packable) {
-            std::sort(key.begin(), key.end());
+            // (equal pairs -- PWM windows, read pairs -- arrive sorted: the test costs one pass, the sort was 1 of the 1.7 ms the
+            // plan of 100 000 windows took)
+            if (!std::is_sorted(key.begin(), key.end())) std::sort(key.begin(), key.end());
             for (size_t j = 0; j < k.n_small; ++j) k.order[j] = (uint32_t)(key[j] & 0xffffffu);
         } else {
             std::stable_sort(k.order.begin(), k.order.end(), [&](uint32_t a, uint32_t b) { return pair_cost(k.descs[a]) > pair_cost(k.descs[b]); });
@@ -1152,7 +1164,9 @@ static void device_pipeline(DevCtx *dev, BatchJob &job)
         bool done_issuing = false;
     } sh;
     sh.slot_free.assign(ns, 1);
-    std::vector<Chunk> plans(ns);                      // the plan of the chunk each slot holds
+    static thread_local std::vector<Chunk> plans_tl;   // (kept from call to call: see Chunk::reset)
+    if (plans_tl.size() < (size_t)ns) plans_tl.resize(ns);
+    std::vector<Chunk> &plans = plans_tl;              // the plan of the chunk each slot holds
     size_t depth = 3;
     if (const char *e = getenv("ALN_FILL_DEPTH")) depth = std::max(1, atoi(e));
     std::thread fetcher([&] {
@@ -1186,7 +1200,7 @@ static void device_pipeline(DevCtx *dev, BatchJob &job)
         const size_t ci = job.next.fetch_add(1);
         if (ci >= nc) break;
         Chunk &k = plans[si];
-        k = Chunk();
+        k.reset();
         // (walk waves beside the LAST chunk's own fill, as a staged batch has them, were measured: 53.7 ms against 52.0 without)
         st = chunk_plan(dev, c, job.q_off, job.q_len, job.t_off, job.t_len, (*job.ranges)[ci].first, (*job.ranges)[ci].second, false, k, nc > 4);
         if (st != ALN_OK) break;
@@ -1236,7 +1250,9 @@ extern "C" int aln_align_batch(aln_ctx *ctx, const aln_params *params, const uin
         Slot *sl[1];
         pool_lease(dev, 1, sl);
         struct Release { DevCtx *c; Slot **s; ~Release() { pool_release(c, s, 1); } } rel{dev, sl};
-        Chunk k;
+        static thread_local Chunk k_tl;              // (kept from call to call: see Chunk::reset)
+        Chunk &k = k_tl;
+        k.reset();
         Slot &s = *sl[0];
         // ALN_TRACE_CALL=1: where the wall clock of a one-chunk call goes (stderr)
         const bool trace = getenv("ALN_TRACE_CALL") != nullptr;
