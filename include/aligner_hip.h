@@ -101,7 +101,10 @@ typedef struct aln_batch aln_batch;  /* a batch of pairs staged in HBM */
  * aln_create: one GPU.  aln_create_multi: the listed GPUs of this process (n_devices = 0: every visible one); single calls go
  * to the devices in turn, a batch call is cut into chunks that the devices take from a common queue, and every device writes
  * its chunks' summaries and strings straight into the caller's host buffers over its own PCIe link (the host array IS the
- * gather; the multi-process form gathers device-side with RCCL, aligner_amd/distributed.py). ---- */
+ * gather; the multi-process form gathers device-side with RCCL, aligner_amd/distributed.py).
+ * Creation warms the context (~0.1 s per GPU in all): the code objects are loaded and one synthetic 1000 x 1000 pair goes through
+ * aln_align_pair, so that the first real call finds pool slot 0, its buffers and every kernel of that route in place (a first
+ * 1000 x 1000 pair: 0.4 ms instead of 26-60; aligner-cli aligns one pair per process).  ALN_NO_WARMUP=1 leaves it to the first call. ---- */
 aln_ctx *aln_create(int device_id, int *status);
 aln_ctx *aln_create_multi(int n_devices, const int *device_ids, int *status);
 int aln_device_count(const aln_ctx *ctx);
