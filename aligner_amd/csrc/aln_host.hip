@@ -49,6 +49,7 @@ extern "C" void aln_launch_validate(const uint8_t *seqs, PairDesc *descs, uint32
                                     hipStream_t s);
 extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_wave(const TraceArgs *a, hipStream_t s);
+extern "C" void aln_launch_scale_results(aln_pair_result *results, uint32_t n, double factor, hipStream_t s);
 extern "C" void aln_launch_traceback_overlap(const TraceArgs *a, uint32_t waves, hipStream_t s);
 extern "C" void aln_launch_traceback_expand(const TraceArgs *a, hipStream_t s);
 extern "C" void aln_launch_traceback_single(const TraceSingleArgs *a, uint32_t N, hipStream_t s);
@@ -340,6 +341,7 @@ struct Call {
     uint32_t outs = 0;
     bool store_dirs = true, want_tb = true, want_h = false;
     bool is_int = true, fast = false; // decided from the whole batch (the longest pair), the same for every chunk
+    double unscale = 1.0;             // dyadic schemes on the integer kernels: scores come back multiplied by this (2^-k), see call_init
     int semantics = 0;                // what the kernels run (PWM runs as CORE_LOCAL with position-specific scoring)
 };
 
@@ -397,6 +399,28 @@ static int call_init(Call &c, const aln_params *p, const uint64_t *q_len, const 
         if (q_len[i] > 0x7FFFFFF0ull || t_len[i] > 0x7FFFFFF0ull) { g_err = "sequence too long"; return ALN_ERR_UNSUPPORTED; }
         const uint64_t N = c.pwm ? c.cols : q_len[i], M = t_len[i];
         if (N && M) max_span = std::max(max_span, N + M + 2);
+    }
+    // Dyadic schemes: when every penalty and score is a multiple of 2^-k (BLOSUM62 in half-bits, del 11.5 ...), the scheme times 2^k
+    // is an integer scheme with the same maxima, the same ties and the same zeros -- in the reference's f64 every H is an exact
+    // multiple of 2^-k, two candidates differ by 0 or by >= 2^-k > f64::EPSILON, and H == 0 means the same -- so the integer kernels
+    // fill it (three times the f64 kernels' rate) and the two scores of every summary are scaled back, exactly, by one small kernel
+    // behind the traceback.  Not with the H output (the dump is what the kernels computed), not when f64 is asked for.
+    // ALN_NO_DYADIC=1: off.
+    if (c.core && !c.all_int && !p->force_f64 && !want_h && !getenv("ALN_NO_DYADIC")) {
+        for (int kk = 1; kk <= 8; ++kk) {
+            const double sc = (double)(1 << kk);
+            bool ok = integral(p->del * sc) && integral(p->ext * sc);
+            for (size_t i = 0; ok && i < c.md.size(); ++i) ok = integral(c.md[i] * sc);
+            if (!ok) continue;
+            if (c.maxabs * sc * (double)max_span < 1073741824.0) {
+                for (double &v : c.md) v *= sc;
+                c.p.del *= sc; c.p.ext *= sc;
+                c.maxabs *= sc; c.smin *= sc; c.smax *= sc;
+                c.all_int = true;
+                c.unscale = 1.0 / sc;
+            }
+            break;
+        }
     }
     // integer kernels are exact iff every value is integral and |H| cannot leave i32
     c.is_int = c.all_int && !p->force_f64 && c.maxabs * (double)max_span < 1073741824.0;
@@ -989,6 +1013,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
         if (batch_tb) aln_launch_traceback_expand(&ta, st);
         HIPCHK(hipGetLastError());
     }
+    if (c.unscale != 1.0) { aln_launch_scale_results(s.results.as<aln_pair_result>(), (uint32_t)k.n, c.unscale, st); HIPCHK(hipGetLastError()); }
     if (ev) HIPCHK(hipEventRecord(ev[2], st));
     if (fill_launches) *fill_launches = launches;
     return ALN_OK;

@@ -2745,6 +2745,16 @@ extern "C" void aln_launch_traceback(const TraceArgs *a, hipStream_t s)
     const uint32_t grid = (a->n_pairs + 63) / 64;
     hipLaunchKernelGGL(aln_traceback_kernel, dim3(grid), dim3(64), 0, s, *a);
 }
+// dyadic schemes filled by the integer kernels (aln_host.hip, call_init): both scores of every summary times 2^-k, exactly
+extern "C" __global__ __launch_bounds__(256) void aln_scale_results_kernel(aln_pair_result *results, uint32_t n, double factor)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && results[i].status == ALN_OK) { results[i].f *= factor; results[i].score *= factor; }
+}
+extern "C" void aln_launch_scale_results(aln_pair_result *results, uint32_t n, double factor, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(aln_scale_results_kernel, dim3((n + 255) / 256), dim3(256), 0, s, results, n, factor);
+}
 extern "C" void aln_launch_traceback_wave(const TraceArgs *a, hipStream_t s)
 {
     hipLaunchKernelGGL(aln_traceback_wave_kernel, dim3((a->n_pairs + 3) / 4), dim3(256), 0, s, *a);

@@ -156,17 +156,18 @@ def small_configs(S, local_rank, stream, torch):
     # kernels; and with the full AlignmentResult (direction matrix from the fast kernels; H only from the generic ones)
     q, t = workloads.c2_pair(homolog=False)
     cells = len(q) * len(t)
-    w = pair_walls(_ffi.CORE_LOCAL, q, t, 11.5, 2.25, S * 0.5, reps=10)
-    out["f64_pair"] = {"workload": "the C2 pair, real-valued matrix (BLOSUM62 x 0.5, del 11.5 / ext 2.25): f64 kernels, one workgroup per pair",
+    w = pair_walls(_ffi.CORE_LOCAL, q, t, 11.5, 2.25, S * 0.5, reps=10, force_f64=True)
+    out["f64_pair"] = {"workload": "the C2 pair, real-valued matrix (BLOSUM62 x 0.5, del 11.5 / ext 2.25), f64 kernels forced (a dyadic scheme: by itself "
+                                   "the library runs it on the integer kernels, see dyadic_batch): one workgroup per pair",
                        "aln_align_pair_wall_ms_median": round(w[len(w) // 2] * 1e3, 3), "gcups": round(cells / w[len(w) // 2] / 1e9, 3)}
     # (that pair needs a second advice pass; most do not: eight more random 1000 x 1000 pairs)
     rng8 = np.random.default_rng(8)
     med, one_pass = [], 0
     for _ in range(8):
         q8, t8 = rng8.integers(0, 20, 1000).astype(np.uint8), rng8.integers(0, 20, 1000).astype(np.uint8)
-        w8 = pair_walls(_ffi.CORE_LOCAL, q8, t8, 11.5, 2.25, S * 0.5, reps=6)
+        w8 = pair_walls(_ffi.CORE_LOCAL, q8, t8, 11.5, 2.25, S * 0.5, reps=6, force_f64=True)
         med.append(w8[len(w8) // 2])
-        one_pass += int((runtime.align_pair(_ffi.CORE_LOCAL, q8, t8, 11.5, 2.25, S * 0.5, device=local_rank)[0].passes & 0x7f) == 1)
+        one_pass += int((runtime.align_pair(_ffi.CORE_LOCAL, q8, t8, 11.5, 2.25, S * 0.5, device=local_rank, force_f64=True)[0].passes & 0x7f) == 1)
     out["f64_pair"]["other_pairs"] = {"what": "8 uniform-random 1000 x 1000 pairs, same scoring", "wall_ms_mean": round(float(np.mean(med)) * 1e3, 3),
                                       "wall_ms_min": round(min(med) * 1e3, 3), "wall_ms_max": round(max(med) * 1e3, 3), "one_pass": one_pass}
     w = pair_walls(_ffi.CORE_LOCAL, q, t, 11, 2, S, reps=10, want_directions=True)
@@ -262,17 +263,20 @@ def small_configs(S, local_rank, stream, torch):
     from aligner_amd.batch import align_batch
     bf = workloads.c5_batch(20000)
     sample = bf.select(range(200))
-    for key, scale, de_, ex_ in (("f64_batch", 0.5, 11.5, 2.25), ("f64_batch_nondyadic", 0.37, 11.3, 2.1)):
+    # dyadic_batch: the dyadic scheme as the library runs it by itself -- on the integer kernels, scores scaled back (exact: DESIGN 4.4)
+    for key, scale, de_, ex_, f64 in (("f64_batch", 0.5, 11.5, 2.25, True), ("f64_batch_nondyadic", 0.37, 11.3, 2.1, False), ("dyadic_batch", 0.5, 11.5, 2.25, False)):
         tsf, rf = [], None
         for _ in range(4):
             t0 = time.perf_counter()
-            rf = align_batch(bf, _ffi.CORE_LOCAL, de_, ex_, S * scale, device=local_rank, want_traceback=True, out=rf)   # the caller keeps its buffers
+            rf = align_batch(bf, _ffi.CORE_LOCAL, de_, ex_, S * scale, device=local_rank, want_traceback=True, out=rf, force_f64=f64)   # the caller keeps its buffers
             tsf.append(time.perf_counter() - t0)
         refs, _, _ = oracle.align_batch(oracle.CORE_LOCAL, sample.seqs, sample.q_off, sample.q_len, sample.t_off, sample.t_len, de_, ex_, S * scale,
                                         max(1, min(cores, 64)))
         same = sum(1 for i in range(len(sample)) if (float(rf.results[i]["score"]), int(rf.results[i]["end_y"]), int(rf.results[i]["end_x"]),
                                                      int(rf.results[i]["aln_len"])) == (refs[i].score, refs[i].end_y, refs[i].end_x, refs[i].aln_len))
-        out[key] = {"workload": "the first 20000 C5 pairs, real-valued matrix (BLOSUM62 x %g, del %g / ext %g): f64 kernels, summaries + strings, host to host" % (scale, de_, ex_),
+        out[key] = {"workload": "the first 20000 C5 pairs, real-valued matrix (BLOSUM62 x %g, del %g / ext %g): %s, summaries + strings, host to host" % (
+                        scale, de_, ex_, "integer kernels (the scheme times 4), scores scaled back" if key == "dyadic_batch" else "f64 kernels" + (" forced" if f64 else "")),
+                    "integer_kernels": bool((rf.results["flags"] & 1).all()),
                     "ms": round(min(tsf[1:]) * 1e3, 2), "gcups": round(bf.cells / min(tsf[1:]) / 1e9, 2), "pairs_ok": int((rf.results["status"] == 0).sum()),
                     "pairs_filled_twice": int(((rf.results["passes"] & 0xff) >= 2).sum()), "sample_pairs_equal_oracle": "%d of %d" % (same, len(sample))}
     return out

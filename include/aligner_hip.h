@@ -88,7 +88,8 @@ typedef struct aln_pair_result {
                                    bits 8-15: localized repairs of strip 0; bits 16-19: 1 + checkpoint at which the last one re-converged;
                                    bits 20-23: why a repair escalated to a full pass (1 hazard beyond the last checkpoint, 2 strip 0's
                                    bottom row moved, 3 no re-convergence, 4 repair limit); diagnostics only */
-    uint32_t flags;             /* bit0: integer kernels were used; bit1: the strip-pipelined single-pair route;
+    uint32_t flags;             /* bit0: integer kernels were used (also for a real-valued scheme whose numbers are all multiples of
+                                   2^-k, k <= 8: it is filled as the integer scheme times 2^k and f / score are scaled back, exactly); bit1: the strip-pipelined single-pair route;
                                    bit2: generic kernels, one workgroup per pair (real-valued matrix / H output, <= 4 pairs per call) */
 } aln_pair_result;
 

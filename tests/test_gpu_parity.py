@@ -226,7 +226,7 @@ def test_generic_kernels_accept_a_pass_whose_new_advice_moves_no_cell_of_row_1(o
         pairs.append((q, t))
         ref = orc.align(_ffi.CORE_LOCAL, q, t, 11.5, 2.25, S, want_matrices=True)
         zeros = bool((ref["H"][M, 1:N] == 0).any())                  # the first pass's advice is not the final one
-        res = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11.5, 2.25, S, directions_only=True)
+        res = check_pair(orc, _ffi.CORE_LOCAL, q, t, 11.5, 2.25, S, directions_only=True, force_f64=True)   # (a dyadic scheme: the integer kernels would take it)
         assert res.flags & 4
         if zeros and (res.passes & 0x7f) == 1:
             one += 1
@@ -234,7 +234,7 @@ def test_generic_kernels_accept_a_pass_whose_new_advice_moves_no_cell_of_row_1(o
             two += 1
     assert one >= 1 and two >= 1, (one, two)
     b = PairBatch.from_pairs(pairs * 3)                              # 30 pairs: the batch kernel
-    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11.5, 2.25, S)
+    got = _check_batch(orc, b, _ffi.CORE_LOCAL, 11.5, 2.25, S, force_f64=True)
     p = got.results["passes"] & 0x7f
     assert (p == 1).any() and (p >= 2).any()
 
@@ -407,6 +407,37 @@ def _same_batch_results(a, b, n, strings_every=1):
         qa, ta = a.aligned(i)
         qb, tb = b.aligned(i)
         assert (qa == qb).all() and (ta == tb).all(), i
+
+
+@pytest.mark.parametrize("sem", [_ffi.CORE_LOCAL, _ffi.CORE_GLOBAL])
+def test_dyadic_schemes_run_on_the_integer_kernels(orc, blosum62, sem):
+    """A real-valued scheme whose numbers are all multiples of 2^-k (BLOSUM62 x 0.5 with 11.5 / 2.25: k = 2; x 0.125 with 1.375 /
+    0.25: k = 3) is an integer scheme scaled by 2^k, exactly: the library fills it with the integer kernels (flags bit 0) and scales
+    the two scores of every summary back.  Same summaries and strings as the oracle on the real-valued scheme and as the f64
+    kernels (force_f64); a scheme that is not dyadic (x 0.3) stays on the f64 kernels; with the H output the scheme is not scaled."""
+    rng = np.random.default_rng(4 + sem)
+    pairs = []
+    for i in range(40):
+        N, M = int(rng.integers(30, 1400)), int(rng.integers(30, 1400))
+        q = rng.integers(0, 20, N).astype(np.uint8)
+        t = rng.integers(0, 20, M).astype(np.uint8)
+        L = min(N, M) // 2
+        t[:L] = q[:L]
+        pairs.append((q, t))
+    pb = PairBatch.from_pairs(pairs)
+    for scale, de, ex in ((0.5, 11.5, 2.25), (0.125, 1.375, 0.25)):
+        S = blosum62 * scale
+        got = _check_batch(orc, pb, sem, de, ex, S)
+        assert (got.results["flags"] & 1).all(), "not on the integer kernels"
+        f64 = align_batch(pb, sem, de, ex, S, force_f64=True)
+        assert not (f64.results["flags"] & 1).any()
+        _same_batch_results(got, f64, len(pb))
+        res = check_pair(orc, sem, pairs[0][0], pairs[0][1], de, ex, S, directions_only=True)      # one pair, directions too
+        assert res.flags & 1
+        res = check_pair(orc, sem, pairs[1][0][:200], pairs[1][1][:150], de, ex, S)                 # with H: the f64 kernels, unscaled
+        assert not (res.flags & 1)
+    got = _check_batch(orc, pb, sem, 11.3, 2.1, blosum62 * 0.3)
+    assert not (got.results["flags"] & 1).any()
 
 
 @pytest.mark.parametrize("claim", ["2", "3", "4"])
@@ -1088,7 +1119,7 @@ def test_pipelined_batch_call_chunks_layouts_and_bad_pairs(orc, blosum62, monkey
     assert sorted(set(got.results["status"].tolist())) == [0, _ffi.ERR_EMPTY_SEQUENCE, _ffi.ERR_CODE_OUT_OF_RANGE]
     _check_batch(orc, bad, _ffi.CORE_GLOBAL, 11, 2, blosum62)
     _check_batch(orc, b, _ffi.LEGACY_LOCAL, 11, 11, blosum62)
-    _check_batch(orc, b, _ffi.CORE_LOCAL, 11.5, 2.25, blosum62 * 0.5)           # f64 kernels
+    _check_batch(orc, b, _ffi.CORE_LOCAL, 11.5, 2.25, blosum62 * 0.5, force_f64=True)           # f64 kernels
     # one chunk again: the same answers
     monkeypatch.delenv("ALN_CHUNK_CELLS")
     got = _check_batch(orc, bad, _ffi.CORE_LOCAL, 11, 2, blosum62)

@@ -1,5 +1,7 @@
 """f64 kernels on a batch: the first `n` C5 pairs with a real-valued matrix (BLOSUM62 x 0.5, del 11.5 / ext 2.25) through
 aln_align_batch, host buffers in and out.  usage: python tools/bench_f64_batch.py [n=4000]"""
+import os
+os.environ.setdefault("ALN_NO_DYADIC", "1")      # this tool is about the f64 kernels: a dyadic scheme stays on them
 import sys, time
 sys.path.insert(0, ".")
 from aligner_amd import _ffi, workloads

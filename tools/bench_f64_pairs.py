@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("ALN_NO_DYADIC", "1")      # this tool is about the f64 kernels: a dyadic scheme stays on them
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,6 +1,8 @@
 """f64 kernels on a batch, resident (one chunk = the whole batch; StagedBatch) next to the pipelined host call: is the f64 batch
 bound by instructions or by balance?  usage: python tools/bench_f64_staged.py [n=20000] [scale=0.5 del=11.5 ext=2.25]   (0.5 / 11.5 / 2.25 is a DYADIC scheme: every score a
 multiple of 0.25, exact zeros everywhere, a third of the pairs fill twice; 0.37 / 11.3 / 2.1 is what a re-estimated matrix looks like)"""
+import os
+os.environ.setdefault("ALN_NO_DYADIC", "1")      # this tool is about the f64 kernels: a dyadic scheme stays on them
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")

@@ -3,6 +3,8 @@ with a real-valued matrix, forced f64, or integers forced off the fast path; eve
 (rows 65..2048: R = 1 / 2 / 4; columns 16..4000: ring wrap-around); zero-rich scoring (several advice passes, strict-order
 fall-back) -- summary, both strings and every direction against the CPU oracle, and the route flag (bit 2).
 usage: python tools/fuzz_wgpipe.py [cases [seed]]"""
+import os
+os.environ.setdefault("ALN_NO_DYADIC", "1")      # this tool is about the f64 kernels: a dyadic scheme stays on them
 import sys
 import numpy as np
 sys.path.insert(0, '.')
