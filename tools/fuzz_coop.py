@@ -26,6 +26,11 @@ for b in range(batches):
     dele, ext = [(11, 2), (2, 1), (3, 1), (11, 1)][int(rng.integers(0, 4))]
     if sem >= 2:
         ext = dele
+    # core semantics: every third batch as a dyadic real-valued scheme (the same scheme divided by 2, 4 or 8: the library scales it
+    # back onto the integer kernels; the oracle computes in f64 on the numbers as given)
+    dyadic = int(rng.integers(1, 4)) if sem < 2 and rng.random() < 0.34 else 0
+    if dyadic:
+        S = S / float(1 << dyadic); dele = dele / float(1 << dyadic); ext = ext / float(1 << dyadic)
     shape = int(rng.integers(0, 4))
     if shape == 0:      # few large pairs: fewer pairs than waves, everything shared
         n = int(rng.integers(2, 60)); lo, hi = 600, 5000
@@ -55,7 +60,7 @@ for b in range(batches):
         else: os.environ[k] = v
     want_tb = rng.random() < 0.8
     print("batch", b, "sem", sem, "pairs", n, "shape", shape, "gaps", dele, ext, "zero_rich", zero_rich, "debug", dbg, "tail", tail, "linger", linger,
-          "traceback", want_tb, "cells %.3g" % pb.cells, flush=True)
+          "traceback", want_tb, "dyadic", dyadic, "cells %.3g" % pb.cells, flush=True)
     got = align_batch(pb, sem, dele, ext, S, want_traceback=want_tb)
     ref, tb, tb_off = orc.align_batch(sem, pb.seqs, pb.q_off, pb.q_len, pb.t_off, pb.t_len, dele, ext, S, 16)
     for i in range(n):
