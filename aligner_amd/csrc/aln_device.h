@@ -97,6 +97,7 @@ struct FillArgs {
     uint32_t coop_linger;            // 1: waves that find the queue dry stay and take strips until every pair has finished
     uint32_t coop_debug;             // testing (ALN_COOP_DEBUG): bit 0 first passes are not opened; bit 1 no hints are posted (the owner
                                      // claims every strip of an open pass itself); bit 2 re-fills keep the skewed layout
+    uint32_t ck_last;                // fast kernels: the last checkpoint step of strip 0 of a hazard pair (512 or ALN_CK_LAST = 1024)
     uint32_t claim;                  // fast kernels without cooperative passes: queue positions a wave takes per atomic (1..4): batches of
                                      // many equal short pairs keep their waves in step, and 3000 waves at one counter within a microsecond
                                      // wait for each other (C3: 14 of the 47 us a wave spends per pair lay between two pairs)
@@ -185,8 +186,11 @@ struct SingleArgs {
     uint32_t mode;            // 0 = a full pass (`pass`, gated by ctrl[1 + pass]); 1 = the repair run (gated by ctrl[8])
 };
 
-// strip 0 of a hazard pair checkpoints its lane state at steps max(16, one quad), then doubling, up to 512
-#define ALN_CK_SLOTS 6
+// strip 0 of a hazard pair checkpoints its lane state at steps max(16, one quad), then doubling, up to 1024 (r02: 512 -- enough for
+// BLOSUM62 11 / 2, whose bottom-row zeros sit next to the left border; under costlier gaps -- BLOSUM62 x 2 with 46 / 9, the integer
+// form of the dyadic scheme x 0.5 with 11.5 / 2.25 -- 41 % of C5's pairs flipped an advice bit beyond column 512 and were re-filled)
+#define ALN_CK_SLOTS 7
+#define ALN_CK_LAST 1024u
 #define ALN_CASCADE_ROWS 3u
 #define ALN_CK_FIRST 16u
 

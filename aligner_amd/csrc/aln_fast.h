@@ -161,6 +161,7 @@ struct FastIn {
     uint32_t tag_base;
     // batch kernels: 0, or (log2 of the time slice in 10 ns ticks) << 8 | the wave's slot in its SIMD (fair_prio)
     uint32_t fair;
+    uint32_t ck_last;         // batch kernels: the last checkpoint step (FillArgs::ck_last)
 };
 
 // The lane's running end-cell candidate (T form) + outcome flags; threaded through the strips by value.
@@ -776,11 +777,11 @@ struct FastStrip {
         // border group of the asm loop does not know: that quad stays with the C++ step
         if (ASMPATH && GLOBAL_ASM && FIRST && kb_steady1 * SPB >= N && kb_steady1 >= kb_steady0 + 4u) kb_steady1 -= 4u;
         // Segment ends: the 2048-step chunks of the end-cell tracker and, for strip 0 of a hazard pair, the
-        // checkpoint steps 64, 128, 256, 512.
+        // checkpoint steps 16 .. 1024.
         // (single-pair kernel: ONE checkpoint, at in.ck_stop -- saved by pass 0, the end of the repair run)
         const bool cks = SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0 && in.ck_stop != 0;
         const bool ckmode = cks || (FIRST && !SINGLE && SEM == ALN_CORE_LOCAL && in.ck_mode != 0);
-        // checkpoints sit on quad boundaries: the first at max(16, one quad of 4 * SPB steps), then doubling up to 512
+        // checkpoints sit on quad boundaries: the first at max(16, one quad of 4 * SPB steps), then doubling up to ALN_CK_LAST
         uint32_t next_ck = cks ? in.ck_stop : ckmode ? ((ALN_CK_FIRST + 4u * SPB - 1u) / (4u * SPB)) * (4u * SPB) : 0xffffffffu, slot = 0, chunk_base = 0;
         chunk0 = 0;
         uint32_t kb = 0;
@@ -848,7 +849,11 @@ struct FastStrip {
                     return o;
                 }
                 ++slot;
-                next_ck = next_ck < 512u ? next_ck * 2u : 0xffffffffu;
+                // (a repair whose last flipped bit lies within the first 512 columns gives up at step 512 as it always did: on C5 the
+                // pairs that have not re-converged by then do not at 1024 either, and the longer try delayed their re-fill --
+                // 6.75 -> 7.0 ms on the 8-way shard; the checkpoint at 1024 is for flips beyond column 512)
+                const uint32_t lim = (in.ck_mode == 2 && in.last_flip <= 512u) ? 512u : in.ck_last;
+                next_ck = next_ck < lim ? next_ck * 2u : 0xffffffffu;
                 // a repair that has run out of checkpoints cannot succeed any more: stop here (the caller re-fills the pair)
                 if (in.ck_mode == 2 && next_ck == 0xffffffffu) return o;
             }

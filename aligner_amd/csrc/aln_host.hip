@@ -882,6 +882,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     { const char *e = getenv("ALN_COOP_LINGER"); fa.coop_linger = e ? (uint32_t)atoi(e) : (k.coop_linger ? 1u : 0u); }
     { const char *e = getenv("ALN_COOP_DEBUG"); fa.coop_debug = e ? (uint32_t)atoi(e) : 0u; }
     { const char *e = getenv("ALN_FAIR"); fa.fair = e ? (uint32_t)atoi(e) : 0u; }
+    { const char *e = getenv("ALN_CK_LAST"); fa.ck_last = (e && atoi(e) == 512) ? 512u : ALN_CK_LAST; }
     // runs of queue positions per atomic: only where pairs are many, short and alike (one strip, <= 2^18 cells), nothing is shared
     // and the queue is not two-ended; about 1.6 runs per wave or more, so that the last round stays as even as with single pairs
     fa.claim = 1;

@@ -1206,7 +1206,7 @@ __device__ __forceinline__ bool fast_work(FastIn in, const FastScratch &fs, cons
             while (!converged && !failed && repairs < 8) {
                 ++repairs;
                 passes += 0x100u;                        // repair rounds are counted in bits 8..15
-                if (last_flip > 512u) { failed = true; passes |= 0x100000u; break; }    // beyond the last checkpoint
+                if (last_flip > a.ck_last) { failed = true; passes |= 0x100000u; break; }    // beyond the last checkpoint
                 in.ck_mode = 2;
                 in.last_flip = last_flip;
                 FastOut ro = o;
@@ -1387,6 +1387,7 @@ void aln_fill_fast_kernel(FillArgs a)
     in.N = 0; in.M = 0; in.q = nullptr; in.t = nullptr; in.dirw = nullptr; in.hazard = false; in.adv_any = false; in.store_dirs = true; in.pwm = false; in.pwm_words = nullptr; in.ck_mode = 0; in.last_flip = 0;
     in.ring_in = nullptr; in.ring_out = nullptr; in.lds_scratch = 0; in.ck_stop = 0; in.wt_dirs = false;
     in.strip_rows = ALN_STRIP_ROWS; in.strip_q16 = 0; in.tag_base = 0;
+    in.ck_last = a.ck_last;
     in.fair = a.fair ? (a.fair << 8) | (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u) : 0u;      // HW_ID[3:0]: the wave's slot in its SIMD
     uint32_t pair = 0, qpos = 0, epoch = 0;
     bool dry = false;
@@ -1601,7 +1602,7 @@ __global__ __launch_bounds__(64 * W) void aln_fill_single_kernel(SingleArgs a)
     if (a.test_drop != 0 && strip + 1 == a.test_drop) return;       // fault injection, see SingleArgs
     FastIn in;
     in.lane = threadIdx.x & 63;
-    in.fair = 0;
+    in.fair = 0; in.ck_last = 512u;
     in.N = desc.N; in.M = desc.M;
     in.q = qseq;
     in.t = a.seqs + desc.t_off;
