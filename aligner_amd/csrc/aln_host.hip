@@ -1111,7 +1111,11 @@ static void make_chunks(const Call &c, const uint64_t *q_len, const uint64_t *t_
     if (const char *e = getenv("ALN_CHUNK_CELLS")) target = std::max(1.0, atof(e));
     // (one chunk up to 2e10 cells: a one-chunk call uploads its residues while it plans and its kernel has the chip to itself -- 12 500
     // C5 pairs, 1.5e10 cells: 8.7 ms against 9.1-9.4 in three chunks; 25 000 pairs, 3e10: 17 against 15.5 in four)
-    if (total <= std::max(1.5 * target, 2.0e10) && ndev == 1) { out.emplace_back(0, n); return; }
+    // -- unless the strings it brings back are many: nothing overlaps that copy in a one-chunk call (100 000 PWM windows with both
+    // strings, 316 MB: 15.3 ms in one chunk, 13.2 in two)
+    double out_bytes = 0;
+    if (c.want_tb) for (size_t i = 0; i < n; ++i) out_bytes += (c.pwm ? 5.0 : 2.0) * ((double)(c.pwm ? c.cols : q_len[i]) + (double)t_len[i] + 2.0);
+    if (total <= std::max(1.5 * target, 2.0e10) && ndev == 1 && out_bytes <= 64.0e6) { out.emplace_back(0, n); return; }
     if (total <= 1.5 * target) { out.emplace_back(0, n); return; }
     size_t first = 0;
     double acc = 0;
