@@ -632,7 +632,23 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         if (packable) {
             // (equal pairs -- PWM windows, read pairs -- arrive sorted: the test costs one pass, the sort was 1 of the 1.7 ms the
             // plan of 100 000 windows took)
-            if (!std::is_sorted(key.begin(), key.end())) std::sort(key.begin(), key.end());
+            if (!std::is_sorted(key.begin(), key.end())) {
+                // LSD radix sort on the bits of the cost that vary, 11 at a time (stable: equal costs keep the index order the keys
+                // were built in); std::sort was 0.35 of the 0.7 ms the plan of 12 500 pairs took
+                uint64_t lo = ~0ull, hi = 0;
+                for (uint64_t v : key) { lo = std::min(lo, v >> 24); hi = std::max(hi, v >> 24); }
+                const uint64_t range = hi - lo;                      // sort by (v >> 24) - lo
+                std::vector<uint64_t> tmp(key.size());
+                uint64_t *src = key.data(), *dst = tmp.data();
+                for (uint32_t shift = 0; shift < 40 && (range >> shift) != 0; shift += 11) {
+                    uint32_t cnt[2049] = {0};
+                    for (size_t j = 0; j < key.size(); ++j) ++cnt[((((src[j] >> 24) - lo) >> shift) & 2047u) + 1u];
+                    for (uint32_t d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+                    for (size_t j = 0; j < key.size(); ++j) dst[cnt[(((src[j] >> 24) - lo) >> shift) & 2047u]++] = src[j];
+                    std::swap(src, dst);
+                }
+                if (src != key.data()) memcpy(key.data(), src, key.size() * sizeof(uint64_t));
+            }
             for (size_t j = 0; j < k.n_small; ++j) k.order[j] = (uint32_t)(key[j] & 0xffffffu);
         } else {
             std::stable_sort(k.order.begin(), k.order.end(), [&](uint32_t a, uint32_t b) { return pair_cost(k.descs[a]) > pair_cost(k.descs[b]); });
