@@ -97,6 +97,7 @@ struct FillArgs {
     uint32_t coop_linger;            // 1: waves that find the queue dry stay and take strips until every pair has finished
     uint32_t coop_debug;             // testing (ALN_COOP_DEBUG): bit 0 first passes are not opened; bit 1 no hints are posted (the owner
                                      // claims every strip of an open pass itself); bit 2 re-fills keep the skewed layout
+    uint32_t duo_qo;                 // aln_fill_duo_kernel: u16 entries of ONE staged query in a wave's LDS (longest query + 72, rounded up to 8)
     uint32_t ck_last;                // fast kernels: the last checkpoint step of strip 0 of a hazard pair (512 or ALN_CK_LAST = 1024)
     uint32_t claim;                  // fast kernels without cooperative passes: queue positions a wave takes per atomic (1..4): batches of
                                      // many equal short pairs keep their waves in step, and 3000 waves at one counter within a microsecond

@@ -443,6 +443,7 @@ struct Chunk {
     size_t n_small = 0;
     uint64_t cells = 0, max_cells = 0, dir_bytes = 0, tb_bytes = 0, tag_bytes = 0, hmat_elems = 0;
     uint32_t max_len = 1, grid = 1, zrow_bytes = 0, lds_bytes = 0, prof_stride = 0, tb_waves = 0, single_max_n = 0, cascade_rows = 1;
+    uint32_t duo_qo = 0;               // != 0: two short pairs per wave (aln_fill_duo_kernel): u16 entries of one staged query
     uint64_t scratch_stride = 0, granule_bytes = 0, tbmap_entries = 0, granule_stride_max = 0;
     size_t counter_bytes = 256;
     bool overlap = false;             // walk waves beside the fill (in-kernel overlapped traceback)
@@ -734,6 +735,23 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
     k.lds_bytes = (uint32_t)(((uint64_t)rows * cols * (c.is_int ? 4 : 8) + 15) & ~15ull);
     k.prof_stride = 0;
     if (c.fast && !pwm) { k.prof_stride = cols * 64u * ALN_FULL_R; k.lds_bytes += 4u * k.prof_stride; }
+    // Two short pairs per wave (core global, read pairs: aln_fill_duo_kernel): every pair of the queue at most 256 rows and 1024
+    // columns, more pairs than resident waves (with fewer, a wave per pair is through sooner), nothing shared, no walk waves beside
+    // the fill, and the staged queries fit beside the profiles with three workgroups per CU.  ALN_NO_DUO=1: off.
+    k.duo_qo = 0;
+    if (c.fast && !pwm && c.semantics == ALN_CORE_GLOBAL && !k.coop && !k.overlap && !getenv("ALN_NO_DUO") &&
+        k.n_small > (uint64_t)ctx->cus * 12u) {
+        uint32_t max_rows = 0, max_cols = 0;
+        for (size_t j = 0; j < k.n_small; ++j) { const PairDesc &d = k.descs[k.order[j]]; max_rows = std::max(max_rows, d.M); max_cols = std::max(max_cols, d.N); }
+        const uint32_t qo = (max_cols + 136u + 7u) & ~7u;
+        const uint32_t lds = (uint32_t)(((uint64_t)rows * cols * 4 + 15) & ~15ull) + 4u * (k.prof_stride + 4u * qo);
+        if (max_rows <= 256u && max_cols <= 1024u && lds <= 52u * 1024u) {
+            k.duo_qo = qo;
+            k.lds_bytes = lds;
+            const uint32_t items = (uint32_t)((k.n_small + 1) / 2);
+            k.grid = std::max(1u, std::min((items + 3u) / 4u, (uint32_t)ctx->cus * 3u));
+        }
+    }
     return ALN_OK;
 }
 
@@ -899,11 +917,13 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     { const char *e = getenv("ALN_COOP_DEBUG"); fa.coop_debug = e ? (uint32_t)atoi(e) : 0u; }
     { const char *e = getenv("ALN_FAIR"); fa.fair = e ? (uint32_t)atoi(e) : 0u; }
     { const char *e = getenv("ALN_CK_LAST"); fa.ck_last = (e && atoi(e) == 512) ? 512u : ALN_CK_LAST; }
+    fa.duo_qo = k.duo_qo;
     // runs of queue positions per atomic: only where pairs are many, short and alike (one strip, <= 2^18 cells), nothing is shared
     // and the queue is not two-ended; about 1.6 runs per wave or more, so that the last round stays as even as with single pairs
     fa.claim = 1;
     if (c.fast && !k.coop && !fa.back_waves && k.max_cells <= (1ull << 18) && k.n_small != 0) {
-        const double per_wave = (double)k.n_small / ((double)std::min(k.grid, (uint32_t)ctx->cus * 3u) * 4.0);     // resident waves
+        // (queue units per resident wave; two pairs per wave: a unit is two pairs)
+        const double per_wave = (double)(k.duo_qo ? (k.n_small + 1) / 2 : k.n_small) / ((double)std::min(k.grid, (uint32_t)ctx->cus * 3u) * 4.0);
         // (measured: C3, 3.3 pairs per wave: runs of 2 fill 0.232 -> 0.204 ms, runs of 3 / 4 0.218 / 0.222 -- the last round gets uneven;
         // 100 000 PWM windows, 32 per wave: runs of 4 cost 4 % -- with many pairs per wave the waves drift apart by themselves)
         fa.claim = (per_wave >= 3.2 && per_wave < 12.0) ? 2u : 1u;

@@ -2555,6 +2555,202 @@ extern "C" void aln_launch_fill_fast_rest(const FillArgs *a, uint32_t grid, uint
 }
 #endif
 #if ALN_TU & ALN_PART_FAST_REST_SOLO
+__device__ __forceinline__ bool lane_is_first_cell(uint32_t j, uint32_t k) { return j == 0u && k == 0u; }
+// ---------------------------------------------------------------- two short pairs per wave (core global: read pairs, C3)
+// One wave per pair leaves a 150 x 150 pair with R = 3 rows per lane: 50 of 64 lanes busy, 49 steps of skew on 150 columns, the
+// per-step feed shared by three cells, and a trip to the queue, the descriptors and the code check for every 22 500 cells.  Here
+// lanes 0..31 hold one pair and lanes 32..63 another, R = ceil(rows / 32) rows per lane (C3: 5): 30 + 30 lanes busy, 29 steps of
+// skew, the feed shared by five cells, half the trips.  What changes against FastStrip::step:
+//   * the row above and the query enter at lane 0 AND lane 32: the border value is computed per lane and selected into the lanes
+//     whose sub-lane is 0; the query code does not flow down the lanes -- both queries are staged in LDS as profile offsets
+//     (zero-padded on both sides) and every lane reads its column's one two steps ahead, its profile word one step ahead;
+//   * every lane stores its direction quads into ITS pair's region at sub-lane j, so each region is an ordinary one-strip region of
+//     the uniform layout with R rows per lane (ALN_LAYOUT_UBATCH | R << 8) in which lanes 32..63 are never read: the walk kernels
+//     do not know about any of this;
+//   * the two pairs may differ in both lengths: a lane masks its cells by its own pair's N, stores only the quads its own region has.
+// No row-1 hazard in the global semantics, no end-cell tracker: the cell is the six instructions of v_cell.
+template <int R>
+__device__ __forceinline__ void duo_fill(const FillArgs &a, uint8_t *prof, uint16_t *qo, const uint32_t qo_stride, const int *S, const int lane,
+                                         const uint32_t N, const uint32_t M, const uint8_t *q, const uint8_t *t, uint4 *dirq, const uint32_t myquads,
+                                         const uint32_t nsteps, const uint32_t maxN, int &corner)
+{
+    constexpr int SPB = (int)aln_spb(R);
+    constexpr int RP = ProfWord<R>::RP;
+    using PW = typename ProfWord<R>::T;
+    const uint32_t j = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
+    const int nd4 = -4 * (int)a.del, ne4 = -4 * (int)a.ext;
+    // ---- the two queries as profile offsets: entry i of a half is column i - 32 (zero outside the query)
+    uint16_t *myqo = qo + h * qo_stride;
+    for (uint32_t i = j; i < maxN + 136u; i += 32u) myqo[i] = (i >= 32u && i - 32u < N) ? (uint16_t)((uint32_t)q[i - 32u] * (64u * RP)) : (uint16_t)0;
+    // ---- this lane's rows, their profile columns, the left border (simple/mod.rs:64-70)
+    int tc[R], Tl[R];
+    const uint32_t yb = j * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t y = yb + 1 + r;
+        tc[r] = (y <= M) ? (int)t[y - 1] * (int)a.cols : 0;
+        Tl[r] = (y == M) ? 2 + (int)(M + 1) * nd4 : 2 + (int)y * nd4;
+    }
+    for (uint32_t c = 0; c < a.cols; ++c) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t bte = (uint32_t)(4 * S[tc[r] + c] - 2) & 0xffu;
+            if (r < 4) lo |= bte << (8 * r); else hi |= bte << (8 * (r - 4));
+        }
+        uint8_t *dst = prof + c * (64 * RP) + lane * RP;
+        if constexpr (RP == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+        else if constexpr (RP == 4) *reinterpret_cast<uint32_t *>(dst) = lo;
+        else if constexpr (RP == 2) *reinterpret_cast<uint16_t *>(dst) = (uint16_t)lo;
+        else *dst = (uint8_t)lo;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *prow = prof + lane * RP;
+    const uint16_t *qmine = myqo + 32u - j;                 // qmine[c] = the offset of column c (0-based; zero for c < 0 or c >= N)
+    int hdiag = (yb == 0) ? 2 : 2 + (int)yb * nd4;          // H[yb][0]
+    int bottom = Tl[R - 1];
+    uint32_t dw = 0;
+    PW pw = *reinterpret_cast<const PW *>(prow + qmine[0]);  // step 0: column -j
+    uint32_t qv = qmine[1];                                  // step 1
+    const uint32_t nkb = ((nsteps + SPB - 1) / SPB + 3u) & ~3u;
+    for (uint32_t kb = 0; kb < nkb; kb += 4) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+        for (uint32_t b4 = 0; b4 < 4; ++b4) {
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((kb + b4) * SPB));
+#pragma unroll
+            for (int kk = 0; kk < SPB; ++kk) {
+                const uint32_t k = k0 + (uint32_t)kk;
+                // the row above: H[0][x] = -x del, the corner H[0][N] = -(N + 1) del (simple/mod.rs:59-62), for sub-lane 0; else the lane above
+                const int top0 = (k + 1 == N) ? 2 + (int)(N + 1) * nd4 : 2 + (int)(k + 1) * nd4;
+                int topIn = shr1_i(top0, bottom);
+                topIn = (j == 0) ? top0 : topIn;
+                const PW pwc = pw;
+                pw = *reinterpret_cast<const PW *>(prow + qv);               // step k + 1
+                qv = qmine[k + 2];                                            // step k + 2
+                const uint32_t xm1 = k - j;
+                if (xm1 < N) {
+                    int top = topIn, diag = hdiag;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int negp = (r == 0 && lane_is_first_cell(j, k)) ? nd4 : ne4;     // del for the first visited cell only (simple/mod.rs:72,88-92)
+                        int key, nt;
+                        const uint32_t w32 = prof_word<R>(pwc, r);
+                        switch (r & 3) {
+                        case 0: v_cell<0>(top, Tl[r], negp, diag, w32, key, nt); break;
+                        case 1: v_cell<1>(top, Tl[r], negp, diag, w32, key, nt); break;
+                        case 2: v_cell<2>(top, Tl[r], negp, diag, w32, key, nt); break;
+                        default: v_cell<3>(top, Tl[r], negp, diag, w32, key, nt); break;
+                        }
+                        dw = __builtin_amdgcn_alignbit((uint32_t)key, dw, 2);
+                        diag = Tl[r];
+                        Tl[r] = nt;
+                        top = nt;
+                    }
+                    hdiag = topIn;
+                    bottom = Tl[R - 1];
+                }
+            }
+            if (b4 == 0) v.x = dw;
+            else if (b4 == 1) v.y = dw;
+            else if (b4 == 2) v.z = dw;
+            else v.w = dw;
+        }
+        if (a.store_dirs && (kb >> 2) < myquads) dirq[(size_t)(kb >> 2) * 64] = v;
+    }
+    // H[M][N] lives in the lane that owns row M
+    const uint32_t rb = (M - 1u) % R;
+    int hb = Tl[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Tl[r];
+    corner = hb;
+}
+
+extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(3, 3)))
+void aln_fill_duo_kernel(FillArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *S = reinterpret_cast<int *>(smem);
+    const int *gm = reinterpret_cast<const int *>(a.matrix);
+    for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
+    // per wave: the profile, then the two staged queries (FillArgs::duo_qo entries each)
+    uint8_t *wbase = smem + ((a.rows * a.cols * 4u + 15u) & ~15u) + wv * (a.prof_stride + 4u * a.duo_qo);
+    uint8_t *prof = wbase;
+    uint16_t *qo = reinterpret_cast<uint16_t *>(wbase + a.prof_stride);
+    const uint32_t h = (uint32_t)lane >> 5;
+    uint32_t run_left = 0, run_pos = 0;
+    const uint32_t n_items = (a.n_pairs + 1u) / 2u, claim = a.claim ? a.claim : 1u;
+    for (;;) {
+        if (run_left == 0u) {
+            unsigned long long v = 0;
+            if (lane == 0) v = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.counter + 4), (unsigned long long)claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            if (f >= n_items) break;
+            run_pos = f; run_left = min(claim, n_items - f);
+        }
+        const uint32_t item = run_pos++;
+        --run_left;
+        // this lane's pair: queue positions 2 item (lanes 0..31) and 2 item + 1 (lanes 32..63; none for the last item of an odd batch)
+        const uint32_t qpos = 2u * item + h;
+        const bool have = qpos < a.n_pairs;
+        const uint32_t pair = have ? a.order[qpos] : 0u;
+        const PairDesc &d = a.descs[pair];
+        int st = have ? d.status : ALN_ERR_INVALID_ARGUMENT;
+        uint32_t N = have ? d.N : 0u, M = have ? d.M : 0u;
+        const uint8_t *q = a.seqs + d.q_off, *t = a.seqs + d.t_off;
+        if (st == ALN_OK) {                                  // residue codes outside the matrix: the reference panics (simple/mod.rs:85)
+            uint32_t worst_q = 0, worst_t = 0;
+            for (uint32_t i = (uint32_t)lane & 31u; i < N; i += 32u) worst_q = max(worst_q, (uint32_t)q[i]);
+            for (uint32_t i = (uint32_t)lane & 31u; i < M; i += 32u) worst_t = max(worst_t, (uint32_t)t[i]);
+            const uint64_t badm = __ballot(worst_q >= a.cols || worst_t >= a.rows);
+            if ((badm >> (32u * h)) & 0xffffffffull) st = ALN_ERR_CODE_OUT_OF_RANGE;
+        }
+        const bool ok = st == ALN_OK;
+        if (!ok) { N = 0; M = 0; }
+        // rows per lane for both: the larger of the two pairs' needs
+        const uint32_t Rl = ok ? (M + 31u) / 32u : 1u;
+        uint32_t R = max((uint32_t)__builtin_amdgcn_readlane((int)Rl, 0), (uint32_t)__builtin_amdgcn_readlane((int)Rl, 32));
+        const uint32_t L = ok ? (M + R - 1u) / R : 0u;
+        const uint32_t st_l = ok ? N + L - 1u : 0u;
+        const uint32_t nsteps = max((uint32_t)__builtin_amdgcn_readlane((int)st_l, 0), (uint32_t)__builtin_amdgcn_readlane((int)st_l, 32));
+        const uint32_t maxN = max((uint32_t)__builtin_amdgcn_readlane((int)N, 0), (uint32_t)__builtin_amdgcn_readlane((int)N, 32));
+        uint4 *dirq = reinterpret_cast<uint4 *>(a.dirs + d.dir_off) + ((uint32_t)lane & 31u);
+        const uint32_t myquads = ok ? aln_strip_blocks(N + 63u, aln_spb(R)) / 4u : 0u;
+        int corner = 0;
+        if (nsteps != 0u) {
+            switch (R) {
+            case 1: duo_fill<1>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            case 2: duo_fill<2>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            case 3: duo_fill<3>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            case 4: duo_fill<4>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            case 5: duo_fill<5>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            case 6: duo_fill<6>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            case 7: duo_fill<7>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            default: duo_fill<8>(a, prof, qo, a.duo_qo, S, lane, N, M, q, t, dirq, myquads, nsteps, maxN, corner); break;
+            }
+        }
+        // the summaries: lane (M - 1) / R of each half holds H[M][N]
+        const uint32_t lb = ok ? (M - 1u) / R : 0u;
+        if (have && ((uint32_t)lane & 31u) == lb) {
+            aln_pair_result &res = a.results[pair];
+            if (!ok) skip_invalid(res, st, 0);
+            else {
+                a.descs[pair].layout = ALN_LAYOUT_UBATCH | (R << 8);
+                write_result<ALN_CORE_GLOBAL>(res, 0.0, 0, 0, (double)(corner >> 2), N, M, 1u, 1u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the LDS of this item is reused by the next
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+extern "C" void aln_launch_fill_duo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(aln_fill_duo_kernel, dim3(grid), dim3(256), lds_bytes, s, *a);
+}
 extern "C" void aln_launch_fill_fast_rest_solo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), b(256);
@@ -2599,11 +2795,13 @@ extern "C" void aln_launch_fill_fast_cl(const FillArgs *a, uint32_t grid, uint32
 extern "C" void aln_launch_fill_fast_rest(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_fill_fast_cl_solo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_fill_fast_rest_solo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
+extern "C" void aln_launch_fill_duo(const FillArgs *a, uint32_t grid, uint32_t lds_bytes, hipStream_t s);
 extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_t grid, uint32_t lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), b(256);
 #define ALN_LAUNCH(SC, SEM) hipLaunchKernelGGL((aln_fill_kernel<SC, SEM>), g, b, lds_bytes, s, *a)
-    if (is_int && fast) {
+    if (is_int && fast && a->duo_qo) aln_launch_fill_duo(a, grid, lds_bytes, s);      // two short pairs per wave (core global)
+    else if (is_int && fast) {
         const bool cl = a->semantics == ALN_CORE_LOCAL && !a->pwm;
         if (a->coop) { if (cl) aln_launch_fill_fast_cl(a, grid, lds_bytes, s); else aln_launch_fill_fast_rest(a, grid, lds_bytes, s); }
         else { if (cl) aln_launch_fill_fast_cl_solo(a, grid, lds_bytes, s); else aln_launch_fill_fast_rest_solo(a, grid, lds_bytes, s); }

@@ -440,6 +440,50 @@ def test_dyadic_schemes_run_on_the_integer_kernels(orc, blosum62, sem):
     assert not (got.results["flags"] & 1).any()
 
 
+def test_two_short_pairs_per_wave(orc, monkeypatch):
+    """Core-global batches of more pairs than resident waves whose pairs all have at most 256 rows and 1024 columns are filled two
+    pairs per wave (aln_fill_duo_kernel: lanes 0..31 one pair, lanes 32..63 another, each pair's directions in its own region in
+    the uniform layout).  An odd number of pairs with every shape in 1..1024 x 1..256 -- so the two halves of a wave differ in both
+    lengths and in the rows per lane they would pick alone --, pairs the reference would panic on in either half, score only and
+    with strings: every summary against the oracle and against the one-pair-per-wave kernels (ALN_NO_DUO), strings of every
+    fifth pair against the oracle."""
+    rng = np.random.default_rng(2222)
+    S = nucleotide_matrix()
+    pairs = []
+    for i in range(6001):
+        N = int(rng.integers(1, 1025)) if i % 9 else int(rng.integers(1, 40))
+        M = int(rng.integers(1, 257)) if i % 11 else int(rng.integers(1, 8))
+        q = rng.integers(0, 4, N).astype(np.uint8)
+        t = rng.integers(0, 4, M).astype(np.uint8)
+        L = min(N, M) // 2
+        t[:L] = q[:L]
+        pairs.append((q, t))
+    pairs[100] = (pairs[100][0], np.full(17, 7, np.uint8))                 # codes outside the matrix, first and second half of a wave
+    pairs[4321] = (np.full(5, 250, np.uint8), pairs[4321][1])
+    pb = PairBatch.from_pairs(pairs)
+    got = align_batch(pb, _ffi.CORE_GLOBAL, 10, 1, S)
+    monkeypatch.setenv("ALN_NO_DUO", "1")
+    solo = align_batch(pb, _ffi.CORE_GLOBAL, 10, 1, S)
+    monkeypatch.delenv("ALN_NO_DUO")
+    _same_batch_results(got, solo, len(pb), strings_every=3)
+    score_only = align_batch(pb, _ffi.CORE_GLOBAL, 10, 1, S, want_traceback=False)
+    assert (score_only.results["score"] == got.results["score"]).all() and (score_only.results["status"] == got.results["status"]).all()
+    ref, tb, tb_off = orc.align_batch(_ffi.CORE_GLOBAL, pb.seqs, pb.q_off, pb.q_len, pb.t_off, pb.t_len, 10, 1, S, 16)
+    assert ref[100].status != 0 and ref[4321].status != 0
+    for i in range(len(pb)):
+        r, g = ref[i], got.results[i]
+        assert int(g["status"]) == r.status, i
+        if r.status:
+            continue
+        assert (g["score"], g["f"], g["end_y"], g["end_x"], g["start_y"], g["start_x"], g["aln_len"]) == \
+            (r.score, r.f, r.end_y, r.end_x, r.start_y, r.start_x, r.aln_len), i
+        if i % 5 == 0:
+            cap = int(pb.q_len[i] + pb.t_len[i]) + 2
+            o = int(tb_off[i])
+            qa, ta = got.aligned(i)
+            assert (qa == tb[o:o + r.aln_len]).all() and (ta == tb[o + cap:o + cap + r.aln_len]).all(), i
+
+
 @pytest.mark.parametrize("claim", ["2", "3", "4"])
 def test_waves_take_runs_of_queue_positions(orc, monkeypatch, claim):
     """Batches of many short, alike pairs (read pairs) let a wave take a run of queue positions per atomic (FillArgs::claim; C3 takes
