@@ -15,6 +15,6 @@ for SET in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ
   rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$NAME -- python3 tools/bench_configs.py > $OUT/pmc_$NAME.log 2>&1
 done
 python3 tools/summarize_prof.py $OUT > $OUT/summary_all.txt 2>&1
-grep -A14 "aln_fill_fast_kernel<0" $OUT/summary_all.txt > $OUT/c3_fill_pmc.txt
+grep -A14 -E "aln_fill_duo_kernel|aln_fill_fast_kernel<0" $OUT/summary_all.txt > $OUT/c3_fill_pmc.txt
 rm -rf $OUT/t1 $OUT/t2 $OUT/pmc_*/
 tail -2 $OUT/bench_configs.log; tail -1 $OUT/bench_single.log; cat $OUT/c3_fill_pmc.txt
