@@ -714,6 +714,12 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         // waves that find the queue dry stay around for strips only when they are what fills the chip: a batch with fewer pairs than
         // resident waves (measured on the 12 500-pair shard: staying costs the waves that still work 0.2 ms of 7)
         k.coop_linger = alone && k.n_small < (uint64_t)resident * 4u;
+        // Chains of strips (every first pass open, two or more strips per pair on average, no more pairs than resident waves) run
+        // with TWO waves per SIMD: a chain is as fast as its slowest strip, and the third wave of a SIMD is the one the arbiter
+        // leaves out (256 / 512 / 1024 pairs of 4200 x 4200, score only: 4.97 / 8.99 / 11.8 -> 4.47 / 7.82 / 10.6 ms; 3072 pairs
+        // 23.9 -> 22.8; 5000 pairs -- a wave per pair -- 32.8 -> 36.1: not there).  ALN_CHAIN_WGS=0: off.
+        if (alone && !k.overlap && tail >= k.n_small && k.n_small <= (uint64_t)resident * 4u && strips >= 2 * k.n_small && !(getenv("ALN_CHAIN_WGS") && atoi(getenv("ALN_CHAIN_WGS")) == 0))
+            k.grid = std::min(k.grid, (uint32_t)ctx->cus * 2u);
     }
     if (const char *e = getenv("ALN_FILL_WGS")) k.grid = std::max(1u, std::min(k.grid, (uint32_t)atoi(e)));   // experiments: fewer resident fill waves
     if (k.coop) k.coop_bytes = 4ull * (ALN_COOP_CTL_WORDS + (((uint64_t)k.grid * 4 + 63) & ~63ull)) + (uint64_t)k.grid * 4 * sizeof(CoopRec);
