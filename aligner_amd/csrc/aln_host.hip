@@ -1273,12 +1273,37 @@ static void device_pipeline(DevCtx *dev, BatchJob &job)
         if (ci >= nc) break;
         Chunk &k = plans[si];
         k.reset();
+        Slot &s = *slots[si];
+        // the first chunk of this pipeline: nothing runs yet, so its residues go up on a helper thread while it is planned (as in a
+        // one-chunk call); every later chunk is planned and uploaded while the chunks before it fill
+        std::thread copier;
+        hipError_t copy_err = hipSuccess;
+        uint64_t lo = ~0ull, hi = 0, sum = 0;
+        bool early = false;
+        if (li == 0 && !getenv("ALN_NO_EARLY_UPLOAD")) {
+            const size_t f0 = (*job.ranges)[ci].first, f1 = f0 + (*job.ranges)[ci].second;
+            for (size_t i = f0; i < f1; ++i) {
+                if (!c.pwm && job.q_len[i]) { lo = std::min(lo, job.q_off[i]); hi = std::max(hi, job.q_off[i] + job.q_len[i]); sum += job.q_len[i]; }
+                if (job.t_len[i]) { lo = std::min(lo, job.t_off[i]); hi = std::max(hi, job.t_off[i] + job.t_len[i]); sum += job.t_len[i]; }
+            }
+            early = lo != ~0ull && (hi - lo) <= 2 * sum + 65536 && hi - lo >= (4u << 20) && hi - lo <= job.need.seq_span;
+            if (early) {
+                if ((st = slot_init(s)) != ALN_OK || (st = dev_ensure(s.seqs, job.need.seq_span + 64, s.pooled)) != ALN_OK) break;
+                copier = std::thread([&] {
+                    copy_err = hipSetDevice(dev->device);
+                    if (copy_err == hipSuccess) copy_err = hipMemcpyAsync(s.seqs.p, job.seqs + lo, hi - lo, hipMemcpyHostToDevice, s.stream);
+                });
+            }
+        }
+        struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{copier};
         // (walk waves beside the LAST chunk's own fill, as a staged batch has them, were measured: 53.7 ms against 52.0 without)
         st = chunk_plan(dev, c, job.q_off, job.q_len, job.t_off, job.t_len, (*job.ranges)[ci].first, (*job.ranges)[ci].second, false, k, nc > 4);
         if (st != ALN_OK) break;
-        Slot &s = *slots[si];
         if ((st = slot_ensure(s, c, k, &job.need)) != ALN_OK) break;
-        if ((st = slot_upload(s, c, k, job.seqs, job.q_off, job.q_len, job.t_off, job.t_len, s.stream)) != ALN_OK) break;
+        if (copier.joinable()) copier.join();
+        if (copy_err != hipSuccess) { st = fail(copy_err, "hipMemcpyAsync(residues)"); break; }
+        const bool seqs_there = early && k.seq_direct && k.seq_lo == lo && k.seq_span == hi - lo;
+        if ((st = slot_upload(s, c, k, job.seqs, job.q_off, job.q_len, job.t_off, job.t_len, s.stream, false, seqs_there)) != ALN_OK) break;
         // At most `depth` fills share the chip: chunk i's fill waits for the fill of chunk i - depth.  With every slot's fill
         // started at once the chunks run in lockstep -- they share the chip equally, reach their tails together (a chunk's
         // largest pairs take as long as the whole chunk), then all walk and copy while nothing fills.  Fewer at a time stay
