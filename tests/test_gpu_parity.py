@@ -460,6 +460,8 @@ def test_two_short_pairs_per_wave(orc, monkeypatch):
         pairs.append((q, t))
     pairs[100] = (pairs[100][0], np.full(17, 7, np.uint8))                 # codes outside the matrix, first and second half of a wave
     pairs[4321] = (np.full(5, 250, np.uint8), pairs[4321][1])
+    pairs[2000] = (pairs[2000][0], np.zeros(0, np.uint8))                  # empty sequences (the reference panics: status 2)
+    pairs[2501] = (np.zeros(0, np.uint8), pairs[2501][1])
     pb = PairBatch.from_pairs(pairs)
     got = align_batch(pb, _ffi.CORE_GLOBAL, 10, 1, S)
     monkeypatch.setenv("ALN_NO_DUO", "1")
@@ -469,7 +471,7 @@ def test_two_short_pairs_per_wave(orc, monkeypatch):
     score_only = align_batch(pb, _ffi.CORE_GLOBAL, 10, 1, S, want_traceback=False)
     assert (score_only.results["score"] == got.results["score"]).all() and (score_only.results["status"] == got.results["status"]).all()
     ref, tb, tb_off = orc.align_batch(_ffi.CORE_GLOBAL, pb.seqs, pb.q_off, pb.q_len, pb.t_off, pb.t_len, 10, 1, S, 16)
-    assert ref[100].status != 0 and ref[4321].status != 0
+    assert ref[100].status != 0 and ref[4321].status != 0 and ref[2000].status != 0 and ref[2501].status != 0
     for i in range(len(pb)):
         r, g = ref[i], got.results[i]
         assert int(g["status"]) == r.status, i
