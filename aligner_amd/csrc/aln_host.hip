@@ -750,9 +750,14 @@ static int chunk_plan(const DevCtx *ctx, const Call &c, const uint64_t *q_off, c
         uint32_t max_rows = 0, max_cols = 0;
         for (size_t j = 0; j < k.n_small; ++j) { const PairDesc &d = k.descs[k.order[j]]; max_rows = std::max(max_rows, d.M); max_cols = std::max(max_cols, d.N); }
         const uint32_t qo = (max_cols + 136u + 7u) & ~7u;
-        const uint32_t lds = (uint32_t)(((uint64_t)rows * cols * 4 + 15) & ~15ull) + 4u * (k.prof_stride + 4u * qo);
+        // (a wave's profile: R = ceil(rows / 32) bytes per lane and code, rounded up to 1 / 2 / 4 / 8 -- 20-letter alphabets fit with
+        // up to 128 rows)
+        const uint32_t rmax = (max_rows + 31u) / 32u, rp = rmax > 4u ? 8u : rmax > 2u ? 4u : std::max(rmax, 1u);
+        const uint32_t prof = cols * 64u * rp;
+        const uint32_t lds = (uint32_t)(((uint64_t)rows * cols * 4 + 15) & ~15ull) + 4u * (prof + 4u * qo);
         if (max_rows <= 256u && max_cols <= 1024u && lds <= 52u * 1024u) {
             k.duo_qo = qo;
+            k.prof_stride = prof;
             k.lds_bytes = lds;
             const uint32_t items = (uint32_t)((k.n_small + 1) / 2);
             k.grid = std::max(1u, std::min((items + 3u) / 4u, (uint32_t)ctx->cus * 3u));

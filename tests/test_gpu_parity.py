@@ -440,6 +440,22 @@ def test_dyadic_schemes_run_on_the_integer_kernels(orc, blosum62, sem):
     assert not (got.results["flags"] & 1).any()
 
 
+def test_two_short_protein_pairs_per_wave(orc, blosum62):
+    """The same kernel with a 24-letter alphabet: the profiles of four waves and the staged queries fit a workgroup's LDS share up to
+    128 rows (R <= 4: four profile bytes per lane and code), so peptide batches run two pairs per wave too; beyond, one per wave."""
+    rng = np.random.default_rng(99)
+    for max_rows in (128, 200):
+        pairs = []
+        for i in range(3500):
+            N, M = int(rng.integers(5, 300)), int(rng.integers(5, max_rows + 1))
+            q = rng.integers(0, 20, N).astype(np.uint8)
+            t = rng.integers(0, 20, M).astype(np.uint8)
+            L = min(N, M) // 2
+            t[:L] = q[:L]
+            pairs.append((q, t))
+        _check_batch(orc, PairBatch.from_pairs(pairs), _ffi.CORE_GLOBAL, 11, 2, blosum62)
+
+
 def test_two_short_pairs_per_wave(orc, monkeypatch):
     """Core-global batches of more pairs than resident waves whose pairs all have at most 256 rows and 1024 columns are filled two
     pairs per wave (aln_fill_duo_kernel: lanes 0..31 one pair, lanes 32..63 another, each pair's directions in its own region in
