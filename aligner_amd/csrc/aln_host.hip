@@ -1030,7 +1030,9 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
             // few pairs: one WAVE per pair, its lanes fetching the direction quads ahead of the path (tb_walk_pair_wave: the walk of
             // 256 pairs of 4200 x 4200 3.7 -> ~1 ms); many pairs: one lane per pair, 64 walks in flight per wave.  ALN_TB_WAVE=0 / 1
             // forces one or the other.
-            bool wave_walk = k.n <= 2048;
+            // (up to 4095 pairs when they are long: 3000 C5 pairs host to host 5.27 -> 4.56 ms, 3072 pairs of 4200 x 4200 27.8 -> 26.3;
+            // from 4096 pairs on the walks of such batches run beside the fill)
+            bool wave_walk = k.n <= 2048 || (k.n < 4096 && k.max_len >= 1024);
             if (const char *e = getenv("ALN_TB_WAVE")) wave_walk = atoi(e) != 0;
             if (wave_walk) aln_launch_traceback_wave(&ta, st);
             else aln_launch_traceback(&ta, st);
