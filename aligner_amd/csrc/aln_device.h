@@ -103,6 +103,7 @@ struct FillArgs {
                                      // many equal short pairs keep their waves in step, and 3000 waves at one counter within a microsecond
                                      // wait for each other (C3: 14 of the 47 us a wave spends per pair lay between two pairs)
     uint32_t fair;                   // fast kernels: 0, or log2 of the time slice (10 ns ticks) in which the waves of a SIMD take turns at stepping down (FastStrip::fair_prio)
+    uint32_t f64_old;                // generic f64 kernels: 1 = run_strip's all-options loop instead of the lean f64 strip (ALN_F64_OLD, testing)
 };
 
 // ---- cooperative passes of the fast batch kernel

@@ -913,6 +913,7 @@ static int slot_launch(DevCtx *ctx, Slot &s, const Call &c, const Chunk &k, hipS
     fa.del = c.p.del; fa.ext = c.p.ext; fa.semantics = c.semantics;
     fa.max_passes = c.p.max_passes; fa.force_serial = c.p.force_serial;
     fa.no_repair = getenv("ALN_NO_REPAIR") ? 1u : 0u;
+    fa.f64_old = getenv("ALN_F64_OLD") ? 1u : 0u;
     fa.max_cells = k.max_cells;
     fa.store_dirs = c.store_dirs ? 1u : 0u;
     fa.pwm = c.pwm ? 1u : 0u;

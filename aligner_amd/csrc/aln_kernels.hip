@@ -209,6 +209,8 @@ struct Wave {
     // running end-cell candidate of this lane (local semantics) and final corner value (global)
     SC bv; uint32_t by, bx;
     SC corner;
+    uint32_t dbg;             // testing (ALN_COOP_DEBUG): bit 3 the lean f64 strip looks for an end-cell candidate in every step; bit 4 its threshold is the lane's best
+    SC bt;                    // lean f64 strip: the best H any lane of the wave has seen in this pass (the tracker's threshold)
 };
 
 // a better-than-b for the local end cell
@@ -364,6 +366,313 @@ __device__ __forceinline__ void run_strip(Wave<SC> &w, const uint32_t strip, con
 #pragma unroll
         for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = Hl[r];
         w.corner = O::rdlane(hb, (int)lb);
+    }
+}
+
+// ---------------------------------------------------------------- the lean f64 strip (r03): core semantics, no H dump
+// run_strip above carries every option of the generic kernels through its inner loop (H dump, int / f64, legacy semantics, PWM or
+// not, first strip or not as run-time flags): 30.6 VALU instructions per cell for f64 in the R = 7 loop (20 in the cell, 74 per
+// step around it, a dozen of them reloads of spilled scalars).  Every real-valued batch runs here instead:
+//   * the cell is ONE asm block of 15 VALU instructions (core local; 11 core global): three adds, two maxes, the two distances of
+//     enums.rs:21-25, their compares against f64::EPSILON and H == 0 as wave masks, the 2-bit tag shifted into the direction word
+//     by two v_addc_co_u32 whose carry-in IS the mask (the word is filled from the bottom and bit-reversed once per block: the
+//     same bits as v_alignbit from the top), the NEXT row's carried penalty selected from this cell's zero mask, and the end-cell
+//     tracker reduced to one compare `h >= best of this lane` whose mask is looked at once per step (the update itself -- the
+//     row-major-first rule of `better` -- runs only in the steps that have a candidate);
+//   * H, the scores and the incoming cell are double-buffered by step parity (SPB is even), so nothing is moved between steps;
+//   * the first-strip / PWM variants are template parameters, the bottom-row zeros of the last strip and row 1's record are
+//     taken from the cells' masks in scalar code.
+// Hazards the assembler does not see inside asm blocks (gfx940+: a VALU-written SGPR needs two wait states before a VALU reads
+// it): every v_cmp result is read by a VALU instruction at least three instructions later, or by SALU (interlocked).  The blocks'
+// s_or / s_andn2 write SCC: it is on every clobber list (left off, a scalar compare of the compiler's own was carried across a block and
+// a record branch went the wrong way -- seen only as extra advice passes, the results stayed right).
+typedef unsigned long long lmask_t;
+
+#define ALN_F64_CELL_HEAD \
+    "v_add_f64 %[a], %[top], %[np]\n\t" \
+    "v_add_f64 %[b], %[left], %[np]\n\t" \
+    "v_add_f64 %[c], %[diag], %[s]\n\t" \
+    "v_max_f64 %[m], %[a], %[b]\n\t" \
+    "v_max_f64 %[m], %[m], %[c]\n\t"
+#define ALN_F64_CELL_LOCAL_TAIL \
+    "v_cmp_eq_f64_e64 %[Z], 0, %[m]\n\t" \
+    "v_add_f64 %[a], %[m], -%[a]\n\t" \
+    "v_add_f64 %[b], %[m], -%[b]\n\t" \
+    "v_cmp_gt_f64_e64 %[A], %[eps], %[a]\n\t" \
+    "v_cmp_gt_f64_e64 %[B], %[eps], %[b]\n\t" \
+    "v_cmp_ge_f64_e64 %[HM], %[m], %[bv]\n\t" \
+    "s_andn2_b64 %[B], %[B], %[A]\n\t" \
+    "s_or_b64 %[B], %[B], %[Z]\n\t" \
+    "s_or_b64 %[A], %[A], %[Z]\n\t" \
+    "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[B]\n\t" \
+    "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[A]"
+#define ALN_F64_CELL_SELNEXT \
+    "\n\tv_cndmask_b32_e64 %[nl], %[nel], %[ndl], %[Z]\n\t" \
+    "v_cndmask_b32_e64 %[nh], %[neh], %[ndh], %[Z]"
+
+// one core-local cell.  negp: minus the carried penalty of THIS cell; negp_next: of the cell below (del iff this H == 0,
+// simple/mod.rs:201-205).  hm: lanes whose H reaches bv (the caller passes the best of the whole wave).  The tag (3 <=> H == 0) is in dw's two lowest bits, bit 1 first.
+template <bool SELNEXT>
+__device__ __forceinline__ void cell_f64_local(const double top, const double left, const double diag, const double s, const double negp,
+                                               const int ndl, const int ndh, const int nel, const int neh, const lmask_t eps, const double bv,
+                                               double &h, uint32_t &dw, lmask_t &hm, double &negp_next)
+{
+    double a, b, c, m;
+    lmask_t A, B, Z, HM;
+    if constexpr (SELNEXT) {
+        int nl, nh;
+        asm(ALN_F64_CELL_HEAD ALN_F64_CELL_LOCAL_TAIL ALN_F64_CELL_SELNEXT
+            : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [m] "=&v"(m), [dw] "+v"(dw), [Z] "=&s"(Z), [A] "=&s"(A), [B] "=&s"(B), [HM] "=&s"(HM),
+              [nl] "=&v"(nl), [nh] "=&v"(nh)
+            : [top] "v"(top), [left] "v"(left), [diag] "v"(diag), [s] "v"(s), [np] "v"(negp), [eps] "s"(eps), [bv] "v"(bv),
+              [ndl] "v"(ndl), [ndh] "v"(ndh), [nel] "v"(nel), [neh] "v"(neh)
+            : "vcc", "scc");
+        negp_next = __hiloint2double(nh, nl);
+    } else {
+        asm(ALN_F64_CELL_HEAD ALN_F64_CELL_LOCAL_TAIL
+            : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [m] "=&v"(m), [dw] "+v"(dw), [Z] "=&s"(Z), [A] "=&s"(A), [B] "=&s"(B), [HM] "=&s"(HM)
+            : [top] "v"(top), [left] "v"(left), [diag] "v"(diag), [s] "v"(s), [np] "v"(negp), [eps] "s"(eps), [bv] "v"(bv)
+            : "vcc", "scc");
+    }
+    h = m; hm = HM;
+}
+
+// The same cell software-pipelined over the rows of a lane (what ships): a wave issues in order, and in the block above every cell
+// ends with v_cmp -> s_or -> v_addc_co, scalar results going straight back into vector instructions, before the next row's first
+// add can issue (measured: 23.4 VALU instructions per cell instead of 30.7 and yet 12 % SLOWER, the VALU 73 % busy instead of 96).
+// Here row r's block carries row r-1's tag work between its own dependent instructions: head0 (row 0), mid (rows 1..R-1), tail.
+// pa / pb / pm: the previous row's a, b and H; zp its zero mask.  Hazard distances as above (v_cmp Z -> the next block's
+// v_cndmask: three instructions; head0 ends in s_nop 1).
+__device__ __forceinline__ void cell_f64_head0(const double top, const double left, const double diag, const double s, const double negp,
+                                               double &a, double &b, double &h, lmask_t &z)
+{
+    double c;
+    asm(ALN_F64_CELL_HEAD
+        "v_cmp_eq_f64_e64 %[Z], 0, %[m]\n\t"
+        "s_nop 1"
+        : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [m] "=&v"(h), [Z] "=&s"(z)
+        : [top] "v"(top), [left] "v"(left), [diag] "v"(diag), [s] "v"(s), [np] "v"(negp));
+}
+__device__ __forceinline__ void cell_f64_mid(const double pm, double &pa, double &pb, const lmask_t zp, const double left, const double diag, const double s,
+                                             const int ndl, const int ndh, const int nel, const int neh, const lmask_t eps, const double bv,
+                                             double &a, double &b, double &h, lmask_t &z, lmask_t &hm, uint32_t &dw)
+{
+    double c;
+    lmask_t A, B;
+    // this row's carried penalty (del iff the cell above is 0, simple/mod.rs:201-205) is a temporary of the block: the halves of a
+    // 64-bit operand cannot be named in inline asm, so it lives in a fixed pair
+    asm("v_cndmask_b32_e64 v126, %[nel], %[ndl], %[ZP]\n\t"
+        "v_cndmask_b32_e64 v127, %[neh], %[ndh], %[ZP]\n\t"
+        "v_add_f64 %[pa], %[pm], -%[pa]\n\t"
+        "v_add_f64 %[a], %[pm], v[126:127]\n\t"
+        "v_add_f64 %[b], %[left], v[126:127]\n\t"
+        "v_add_f64 %[pb], %[pm], -%[pb]\n\t"
+        "v_add_f64 %[c], %[diag], %[s]\n\t"
+        "v_cmp_gt_f64_e64 %[A], %[eps], %[pa]\n\t"
+        "v_max_f64 %[m], %[a], %[b]\n\t"
+        "v_cmp_gt_f64_e64 %[B], %[eps], %[pb]\n\t"
+        "v_cmp_ge_f64_e64 %[HM], %[pm], %[bv]\n\t"
+        "v_max_f64 %[m], %[m], %[c]\n\t"
+        "s_andn2_b64 %[B], %[B], %[A]\n\t"
+        "s_or_b64 %[B], %[B], %[ZP]\n\t"
+        "v_cmp_eq_f64_e64 %[Z], 0, %[m]\n\t"
+        "s_or_b64 %[A], %[A], %[ZP]\n\t"
+        "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[B]\n\t"
+        "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[A]"
+        : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [m] "=&v"(h), [pa] "+v"(pa), [pb] "+v"(pb), [dw] "+v"(dw), [Z] "=&s"(z), [A] "=&s"(A), [B] "=&s"(B),
+          [HM] "=&s"(hm)
+        : [pm] "v"(pm), [left] "v"(left), [diag] "v"(diag), [s] "v"(s), [ZP] "s"(zp), [eps] "s"(eps), [bv] "v"(bv),
+          [ndl] "v"(ndl), [ndh] "v"(ndh), [nel] "v"(nel), [neh] "v"(neh)
+        : "vcc", "scc", "v126", "v127");
+}
+__device__ __forceinline__ void cell_f64_tail(const double pm, double &pa, double &pb, const lmask_t zp, const lmask_t eps, const double bv,
+                                              lmask_t &hm, uint32_t &dw)
+{
+    lmask_t A, B;
+    asm("v_add_f64 %[pa], %[pm], -%[pa]\n\t"
+        "v_add_f64 %[pb], %[pm], -%[pb]\n\t"
+        "v_cmp_ge_f64_e64 %[HM], %[pm], %[bv]\n\t"
+        "v_cmp_gt_f64_e64 %[A], %[eps], %[pa]\n\t"
+        "v_cmp_gt_f64_e64 %[B], %[eps], %[pb]\n\t"
+        "s_andn2_b64 %[B], %[B], %[A]\n\t"
+        "s_or_b64 %[B], %[B], %[ZP]\n\t"
+        "s_or_b64 %[A], %[A], %[ZP]\n\t"
+        "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[B]\n\t"
+        "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[A]"
+        : [pa] "+v"(pa), [pb] "+v"(pb), [dw] "+v"(dw), [A] "=&s"(A), [B] "=&s"(B), [HM] "=&s"(hm)
+        : [pm] "v"(pm), [ZP] "s"(zp), [eps] "s"(eps), [bv] "v"(bv)
+        : "vcc", "scc");
+}
+// one core-global cell: no Beginning, no end-cell tracker (simple/mod.rs:72-97)
+__device__ __forceinline__ void cell_f64_global(const double top, const double left, const double diag, const double s, const double negp,
+                                                const lmask_t eps, double &h, uint32_t &dw)
+{
+    double a, b, c, m;
+    lmask_t A, B;
+    asm(ALN_F64_CELL_HEAD
+        "v_add_f64 %[a], %[m], -%[a]\n\t"
+        "v_add_f64 %[b], %[m], -%[b]\n\t"
+        "v_cmp_gt_f64_e64 %[A], %[eps], %[a]\n\t"
+        "v_cmp_gt_f64_e64 %[B], %[eps], %[b]\n\t"
+        "s_andn2_b64 %[B], %[B], %[A]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[B]\n\t"
+        "v_addc_co_u32_e64 %[dw], vcc, %[dw], %[dw], %[A]"
+        : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [m] "=&v"(m), [dw] "+v"(dw), [A] "=&s"(A), [B] "=&s"(B)
+        : [top] "v"(top), [left] "v"(left), [diag] "v"(diag), [s] "v"(s), [np] "v"(negp), [eps] "s"(eps)
+        : "vcc", "scc");
+    h = m;
+}
+
+// one wave step.  Hi / Ho: the lane's R cells of the previous / this column; si / so: this step's scores / the next step's
+// (read from LDS while this one computes); tprev / tcur: the cell above the lane's first row, previous / this column.
+template <int SEM, int R, bool FIRST, bool PWM>
+__device__ __forceinline__ void f64_step(Wave<double> &w, const uint32_t k, const double (&Hi)[R], double (&Ho)[R], const double (&si)[R], double (&so)[R],
+                                     const double tprev, double &tcur, const int (&tc)[R], double &inchunk, uint32_t &advchunk, int &qchunk, int &qoff,
+                                     uint32_t &dw, const uint32_t yb, const uint32_t lb, const uint32_t rb, const double nd, const double ne,
+                                     const int ndl, const int ndh, const int nel, const int neh, const lmask_t eps, const bool last)
+{
+    const uint32_t N = w.N, M = w.M;
+    const int lane = w.lane;
+    if ((k & 63u) == 0) {                          // wave-uniform: next 64 columns of the incoming row, of the advice, of the query
+        const uint32_t xi = k + 1 + (uint32_t)lane;
+        if (!FIRST) inchunk = (xi <= N) ? w.brow[xi] : 0.0;
+        if (SEM == ALN_CORE_LOCAL && FIRST && w.hazard) advchunk = (xi <= N) ? w.advice[xi] : 0u;
+        if (!PWM) qchunk = (xi < N) ? (int)w.q[xi] : 0;
+    }
+    const double top0 = FIRST ? border_top<double, SEM>(k + 1, N, w.del) : ScOps<double>::rdlane(inchunk, (int)(k & 63u));
+    const double topIn = ScOps<double>::shr1(top0, Hi[R - 1]);
+    const uint32_t adv = (SEM == ALN_CORE_LOCAL && FIRST) ? (uint32_t)__builtin_amdgcn_readlane((int)advchunk, (int)(k & 63u)) : 0u;
+    const uint32_t xm1 = k - (uint32_t)lane;
+    if (PWM) qoff = (int)min(xm1 + 1u, N - 1u);
+    else qoff = __builtin_amdgcn_update_dpp(__builtin_amdgcn_readlane(qchunk, (int)(k & 63u)), qoff, 0x138, 0xf, 0xf, false);
+#pragma unroll
+    for (int r = 0; r < R; ++r) so[r] = w.S[tc[r] + qoff];
+    lmask_t hit = 0;
+    if (xm1 < N) {
+        const bool row1 = FIRST && lane == 0;
+        if constexpr (SEM == ALN_CORE_LOCAL) {
+            const bool zr0 = row1 ? (k == 0 || adv != 0) : (topIn == 0.0);
+            const double negp = zr0 ? nd : ne;
+            lmask_t zp, hm;
+            double pa, pb;
+            const double thr = (w.dbg & 16u) ? w.bv : w.bt;
+            cell_f64_head0(topIn, Hi[0], tprev, si[0], negp, pa, pb, Ho[0], zp);
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                double na, nb;
+                lmask_t zn;
+                cell_f64_mid(Ho[r - 1], pa, pb, zp, Hi[r], Hi[r - 1], si[r], ndl, ndh, nel, neh, eps, thr, na, nb, Ho[r], zn, hm, dw);
+                hit |= hm;
+                pa = na; pb = nb; zp = zn;
+            }
+            cell_f64_tail(Ho[R - 1], pa, pb, zp, eps, thr, hm, dw);
+            hit |= hm;
+            // this step's tags sit in dw's low 2 R bits, row r at bits 2 (R-1-r) .. +1 as (b1, b0) from the bottom: 3 <=> H == 0
+            if (FIRST && w.hazard && k < N) {      // row 1 as this pass computed it (adopt_advice_checked); lane 0's x is k + 1
+                const uint32_t t = (dw >> (2 * (R - 1))) & 3u;
+                if (lane == 0) { w.row1[k + 1] = Ho[0]; w.row1tag[k + 1] = (uint8_t)(((t & 1u) << 1) | (t >> 1)); }
+            }
+            if (last && w.hazard && k - lb < N) {  // bottom-row zeros: row rb of lane lb, whose x is k - lb + 1
+                if ((uint32_t)lane == lb) w.zrow[k - lb + 1] = (uint8_t)((((dw >> (2u * ((uint32_t)R - 1u - rb))) & 3u) == 3u) ? 1 : 0);
+            }
+        } else {
+            double negp = (row1 && k == 0) ? nd : ne, top = topIn;      // `del` for the first visited cell only (simple/mod.rs:72,88-92)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                cell_f64_global(top, Hi[r], r ? Hi[r - 1] : tprev, si[r], negp, eps, Ho[r], dw);
+                negp = ne;
+                top = Ho[r];
+            }
+        }
+        if (!last && k - 63u < N) {                // hand the bottom row to the next strip: lane 63's x is k - 62
+            if (lane == 63) w.brow[k - 62u] = Ho[R - 1];
+        }
+    }
+    if (SEM == ALN_CORE_LOCAL && (w.dbg & 8u)) hit = 1;
+    if (SEM == ALN_CORE_LOCAL && hit != 0) {       // wave-uniform: some cell reaches the best the wave has seen (rare: records and ties).
+        const uint32_t x = xm1 + 1;                // Outside the active-lane region: the reduction below is over all 64 lanes.
+        const bool act = xm1 < N;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (__any(act && Ho[r] >= w.bt)) {
+                const uint32_t y = yb + 1 + (uint32_t)r;
+                // first maximum in row-major order, simple/mod.rs:212; every cell that has the final maximum passes here
+                if (act && y <= M && Ho[r] >= w.bt && (w.bx == 0 || better<double, SEM>(Ho[r], y, x, w.bv, w.by, w.bx))) { w.bv = Ho[r]; w.by = y; w.bx = x; }
+            }
+        }
+        double t = w.bv;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) t = max_f64_raw(t, ScOps<double>::xshfl(t, m));
+        w.bt = max_f64_raw(w.bt, t);
+    }
+    tcur = topIn;
+}
+
+template <int SEM, int R, bool FIRST, bool PWM>
+__device__ __forceinline__ void f64_strip(Wave<double> &w, const uint32_t strip, const bool last)
+{
+    const uint32_t N = w.N, M = w.M;
+    const int lane = w.lane;
+    int tc[R];
+    double inchunk;
+    uint32_t advchunk, dw;
+    int qchunk, qoff;
+    constexpr int SPB = (int)aln_spb(R);
+    static_assert(SPB % 2 == 0, "steps are double-buffered in pairs");
+    const uint32_t y0 = strip * ALN_STRIP_ROWS;
+    const uint32_t rows = min(M - y0, (uint32_t)(64 * R));
+    const uint32_t L = (rows + R - 1) / R;
+    const uint32_t nsteps = N + L - 1;
+    const uint32_t yb = y0 + (uint32_t)lane * R;
+    const uint32_t lb = (rows - 1) / R, rb = (rows - 1) % R;
+    double nd = -w.del, ne = -w.ext;
+    // the penalties live in vector registers for the whole strip (left alone the compiler rebuilds them from scalars every step)
+    int ndl = __double2loint(nd), ndh = __double2hiint(nd), nel = __double2loint(ne), neh = __double2hiint(ne);
+    asm volatile("" : "+v"(ndl), "+v"(ndh), "+v"(nel), "+v"(neh));
+    nd = __hiloint2double(ndh, ndl); ne = __hiloint2double(neh, nel);
+    const lmask_t eps = (lmask_t)__double_as_longlong(DBL_EPSILON);
+    double HA[R], HB[R], SA[R], SB[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t y = yb + 1 + r;
+        tc[r] = (y <= M) ? (int)w.t[y - 1] * (int)w.cols : 0;
+        HA[r] = HB[r] = border_left<double, SEM>(y, M, w.del);
+    }
+    double tA = border_left<double, SEM>(yb, M, w.del), tB = tA;      // H[yb][0]
+    inchunk = 0.0; advchunk = 0; qchunk = 0;
+    qoff = PWM ? 0 : ((lane == 0) ? (int)w.q[0] : 0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { SA[r] = w.S[tc[r] + qoff]; SB[r] = SA[r]; }
+    uint32_t *dirw = w.dirw + (strip * aln_strip_bytes(N)) / 4;
+    const uint32_t nkb = (nsteps + SPB - 1) / SPB;
+    for (uint32_t kb = 0; kb < nkb; ++kb) {
+        dw = 0;
+#pragma unroll
+        for (int kk = 0; kk < SPB; kk += 2) {
+            f64_step<SEM, R, FIRST, PWM>(w, kb * SPB + kk, HA, HB, SA, SB, tA, tB, tc, inchunk, advchunk, qchunk, qoff, dw, yb, lb, rb, nd, ne, ndl, ndh, nel, neh, eps, last);
+            f64_step<SEM, R, FIRST, PWM>(w, kb * SPB + kk + 1, HB, HA, SB, SA, tB, tA, tc, inchunk, advchunk, qchunk, qoff, dw, yb, lb, rb, nd, ne, ndl, ndh, nel, neh, eps, last);
+        }
+        if (w.store_dirs) dirw[aln_dir_word_index(kb * SPB, (uint32_t)lane, SPB)] = __builtin_bitreverse32(dw);
+    }
+    if (last) {                                    // H[M][N]: lane lb, row rb, written by that lane's last step lb + N - 1
+        const bool inB = ((lb + N - 1) & 1u) == 0;  // even steps write HB
+        double hb = inB ? HB[0] : HA[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) if ((uint32_t)r == rb) hb = inB ? HB[r] : HA[r];
+        w.corner = ScOps<double>::rdlane(hb, (int)lb);
+    }
+}
+
+template <int SEM, int R>
+__device__ __forceinline__ void run_strip_f64(Wave<double> &w, const uint32_t strip, const bool last)
+{
+    if (strip == 0) {
+        if (w.pwm) f64_strip<SEM, R, true, true>(w, strip, last);
+        else f64_strip<SEM, R, true, false>(w, strip, last);
+    } else {
+        if (w.pwm) f64_strip<SEM, R, false, true>(w, strip, last);
+        else f64_strip<SEM, R, false, false>(w, strip, last);
     }
 }
 
@@ -529,7 +838,7 @@ __device__ __forceinline__ void write_result(aln_pair_result &res, double best, 
 }
 
 // ---------------------------------------------------------------- one pair, generic kernels (int32 without the profile, f64)
-template <typename SC, int SEM>
+template <typename SC, int SEM, bool LEAN = false>
 __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc &desc, aln_pair_result &res)
 {
     using O = ScOps<SC>;
@@ -561,10 +870,26 @@ __device__ __forceinline__ void do_pair(Wave<SC> &w, const FillArgs &a, PairDesc
         do {
             w.bv = (SEM == ALN_LEGACY_LOCAL) ? (SC)-1 : O::lowest();
             w.by = 0; w.bx = 0;
+            w.bt = w.bv;
             for (uint32_t s = 0; s < ns; ++s) {
                 const bool last = (s + 1 == ns);
                 if (s > 0) __threadfence_block();      // strip s reads the boundary row strip s-1 stored
                 const int R = last ? aln_pick_r(M - s * ALN_STRIP_ROWS) : ALN_FULL_R;
+                if constexpr (LEAN) {                  // aln_fill_f64_kernel: the lean f64 strip only
+                    {
+                        switch (R) {
+                        case 1: run_strip_f64<SEM, 1>(w, s, last); break;
+                        case 2: run_strip_f64<SEM, 2>(w, s, last); break;
+                        case 3: run_strip_f64<SEM, 3>(w, s, last); break;
+                        case 4: run_strip_f64<SEM, 4>(w, s, last); break;
+                        case 5: run_strip_f64<SEM, 5>(w, s, last); break;
+                        case 6: run_strip_f64<SEM, 6>(w, s, last); break;
+                        case 7: run_strip_f64<SEM, 7>(w, s, last); break;
+                        default: run_strip_f64<SEM, 8>(w, s, last); break;
+                        }
+                        continue;
+                    }
+                }
                 switch (R) {
                 case 1: run_strip<SC, SEM, 1>(w, s, last); break;
                 case 2: run_strip<SC, SEM, 2>(w, s, last); break;
@@ -1342,6 +1667,7 @@ __global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
     w.row1tag = reinterpret_cast<uint8_t *>(w.row1) + brow_bytes;
     w.S = S;
     w.cols = a.cols;
+    w.dbg = a.coop_debug;
     w.del = ScOps<SC>::from_double(a.del);
     w.ext = ScOps<SC>::from_double(a.ext);
     uint32_t pair, qpos;
@@ -1351,6 +1677,45 @@ __global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
         if (desc.status != ALN_OK) skip_invalid(res, desc.status, w.lane);
         else if (!pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, w.lane)) skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, w.lane);
         else do_pair<SC, SEM>(w, a, desc, res);
+        pair_done(a, w.lane, pair, true);
+    }
+}
+
+// The real-valued batch (core semantics, no H dump): the same kernel around the lean f64 strip alone -- without run_strip's all-options
+// loop in it the kernel fits 128 registers, four waves per SIMD instead of three (the f64 cell chain is latency-bound per wave).
+template <int SEM>
+__global__ __launch_bounds__(256, 4) void aln_fill_f64_kernel(FillArgs a)
+{
+    using SC = double;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SC *S = reinterpret_cast<SC *>(smem);
+    const SC *gm = reinterpret_cast<const SC *>(a.matrix);
+    for (uint32_t i = threadIdx.x; i < a.rows * a.cols; i += blockDim.x) S[i] = gm[i];
+    __syncthreads();
+
+    Wave<SC> w;
+    w.lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint8_t *sc = a.scratch + (uint64_t)wave * a.scratch_stride;
+    const uint64_t brow_bytes = ((uint64_t)(a.max_len + 66) * sizeof(SC) + 63) & ~(uint64_t)63;
+    const uint64_t adv_bytes = ((uint64_t)a.max_len + 66 + 63) & ~(uint64_t)63;
+    w.brow = reinterpret_cast<SC *>(sc);
+    w.advice = sc + brow_bytes;
+    w.zrow = sc + brow_bytes + adv_bytes;                 // a.zrow_bytes >= adv_bytes
+    w.row1 = reinterpret_cast<SC *>(w.zrow + a.zrow_bytes);
+    w.row1tag = reinterpret_cast<uint8_t *>(w.row1) + brow_bytes;
+    w.S = S;
+    w.cols = a.cols;
+    w.dbg = a.coop_debug;
+    w.del = ScOps<SC>::from_double(a.del);
+    w.ext = ScOps<SC>::from_double(a.ext);
+    uint32_t pair, qpos;
+    while (next_pair(a, w.lane, pair, qpos)) {
+        PairDesc &desc = a.descs[pair];
+        aln_pair_result &res = a.results[pair];
+        if (desc.status != ALN_OK) skip_invalid(res, desc.status, w.lane);
+        else if (!pair_codes_ok(a.seqs, desc, a.rows, a.cols, a.pwm != 0, w.lane)) skip_invalid(res, ALN_ERR_CODE_OUT_OF_RANGE, w.lane);
+        else do_pair<SC, SEM, true>(w, a, desc, res);
         pair_done(a, w.lane, pair, true);
     }
 }
@@ -2813,7 +3178,10 @@ extern "C" void aln_launch_fill(const FillArgs *a, int is_int, int fast, uint32_
         default: ALN_LAUNCH(int, ALN_LEGACY_LOCAL); break;
         }
     } else {
-        if (a->semantics == ALN_CORE_GLOBAL) ALN_LAUNCH(double, ALN_CORE_GLOBAL);
+        const bool lean = a->hmat == nullptr && !a->f64_old;
+        if (lean && a->semantics == ALN_CORE_GLOBAL) hipLaunchKernelGGL((aln_fill_f64_kernel<ALN_CORE_GLOBAL>), g, b, lds_bytes, s, *a);
+        else if (lean) hipLaunchKernelGGL((aln_fill_f64_kernel<ALN_CORE_LOCAL>), g, b, lds_bytes, s, *a);
+        else if (a->semantics == ALN_CORE_GLOBAL) ALN_LAUNCH(double, ALN_CORE_GLOBAL);
         else ALN_LAUNCH(double, ALN_CORE_LOCAL);
     }
 #undef ALN_LAUNCH

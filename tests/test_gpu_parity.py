@@ -659,6 +659,29 @@ def test_long_pairs_beyond_the_old_column_limit(orc, blosum62):
         assert qa.tolist() == ref["qa"].tolist() and ta.tolist() == ref["ta"].tolist()
 
 
+@pytest.mark.parametrize("sem", [_ffi.CORE_LOCAL, _ffi.CORE_GLOBAL])
+def test_pairs_beyond_the_single_route_column_limit(orc, blosum62, sem):
+    """Above ~77 000 columns the single-pair route cannot stage the query's profile offsets in LDS and the pair stays in the
+    batch kernel (aln_host.hip, routing); the reference's only limit is memory (simple/mod.rs:53-57).  110 000 columns x
+    700 rows (two strips of the batch layout), its transpose (1719 strips: the single-pair route again), and 131 200 x 130
+    (one strip), alone and as a three-pair batch: summaries and both strings against the oracle."""
+    rng = np.random.default_rng(7707)
+    pairs = []
+    for N, M in [(110000, 700), (700, 110000), (131200, 130)]:
+        q = rng.integers(0, 20, N).astype(np.uint8)
+        t = workloads.mutate(q[:M] if M <= N else np.concatenate([q, rng.integers(0, 20, M - N).astype(np.uint8)]),
+                             99 + N, 20, 0.10, 0.02, out_len=M)
+        pairs.append((q, t))
+    for q, t in pairs:
+        ref = orc.align(sem, q, t, 11, 2, blosum62)
+        res, qa, ta, _, _ = runtime.align_pair(sem, q, t, 11, 2, blosum62)
+        assert res.status == 0 and ref["status"] == 0
+        assert (res.score, res.f, (res.end_y, res.end_x), (res.start_y, res.start_x)) == (ref["score"], ref["f"], ref["end"], ref["start"])
+        assert qa.tolist() == ref["qa"].tolist() and ta.tolist() == ref["ta"].tolist()
+    b = PairBatch.from_pairs(pairs)
+    _check_batch(orc, b, sem, 11, 2, blosum62)
+
+
 def test_c5_sample_matches_oracle(orc, blosum62):
     """BASELINE C5 at its real lengths (200..2000 aa) on a 1500-pair sample: every summary and both aligned strings.
     Exercises multi-strip pairs, the checkpointed first pass and the localized row-1 repair."""
