@@ -209,7 +209,6 @@ struct Wave {
     // running end-cell candidate of this lane (local semantics) and final corner value (global)
     SC bv; uint32_t by, bx;
     SC corner;
-    uint32_t dbg;             // testing (ALN_COOP_DEBUG): bit 3 the lean f64 strip looks for an end-cell candidate in every step; bit 4 its threshold is the lane's best
     SC bt;                    // lean f64 strip: the best H any lane of the wave has seen in this pass (the tracker's threshold)
 };
 
@@ -556,17 +555,16 @@ __device__ __forceinline__ void f64_step(Wave<double> &w, const uint32_t k, cons
             const double negp = zr0 ? nd : ne;
             lmask_t zp, hm;
             double pa, pb;
-            const double thr = (w.dbg & 16u) ? w.bv : w.bt;
             cell_f64_head0(topIn, Hi[0], tprev, si[0], negp, pa, pb, Ho[0], zp);
 #pragma unroll
             for (int r = 1; r < R; ++r) {
                 double na, nb;
                 lmask_t zn;
-                cell_f64_mid(Ho[r - 1], pa, pb, zp, Hi[r], Hi[r - 1], si[r], ndl, ndh, nel, neh, eps, thr, na, nb, Ho[r], zn, hm, dw);
+                cell_f64_mid(Ho[r - 1], pa, pb, zp, Hi[r], Hi[r - 1], si[r], ndl, ndh, nel, neh, eps, w.bt, na, nb, Ho[r], zn, hm, dw);
                 hit |= hm;
                 pa = na; pb = nb; zp = zn;
             }
-            cell_f64_tail(Ho[R - 1], pa, pb, zp, eps, thr, hm, dw);
+            cell_f64_tail(Ho[R - 1], pa, pb, zp, eps, w.bt, hm, dw);
             hit |= hm;
             // this step's tags sit in dw's low 2 R bits, row r at bits 2 (R-1-r) .. +1 as (b1, b0) from the bottom: 3 <=> H == 0
             if (FIRST && w.hazard && k < N) {      // row 1 as this pass computed it (adopt_advice_checked); lane 0's x is k + 1
@@ -589,7 +587,6 @@ __device__ __forceinline__ void f64_step(Wave<double> &w, const uint32_t k, cons
             if (lane == 63) w.brow[k - 62u] = Ho[R - 1];
         }
     }
-    if (SEM == ALN_CORE_LOCAL && (w.dbg & 8u)) hit = 1;
     if (SEM == ALN_CORE_LOCAL && hit != 0) {       // wave-uniform: some cell reaches the best the wave has seen (rare: records and ties).
         const uint32_t x = xm1 + 1;                // Outside the active-lane region: the reduction below is over all 64 lanes.
         const bool act = xm1 < N;
@@ -1667,7 +1664,6 @@ __global__ __launch_bounds__(256, 3) void aln_fill_kernel(FillArgs a)
     w.row1tag = reinterpret_cast<uint8_t *>(w.row1) + brow_bytes;
     w.S = S;
     w.cols = a.cols;
-    w.dbg = a.coop_debug;
     w.del = ScOps<SC>::from_double(a.del);
     w.ext = ScOps<SC>::from_double(a.ext);
     uint32_t pair, qpos;
@@ -1706,7 +1702,6 @@ __global__ __launch_bounds__(256, 4) void aln_fill_f64_kernel(FillArgs a)
     w.row1tag = reinterpret_cast<uint8_t *>(w.row1) + brow_bytes;
     w.S = S;
     w.cols = a.cols;
-    w.dbg = a.coop_debug;
     w.del = ScOps<SC>::from_double(a.del);
     w.ext = ScOps<SC>::from_double(a.ext);
     uint32_t pair, qpos;

@@ -197,6 +197,26 @@ def small_configs(S, local_rank, stream, torch):
                                  "host buffers in and out" + (", numbered + residue strings of every window fetched" if tbk else ""),
                      "ms": round(dtw * 1e3, 2), "gcups": round(100000 * 330 * 300 / dtw / 1e9, 2),
                      "windows_ok": int((resw["status"] == 0).sum())}
+    # the same windows against a REAL-VALUED PWM (latent-repeat-search re-estimates its weights: reals, engine/calc.rs:107-136): the f64
+    # kernels (the lean f64 strip, r03); every 997th window against the oracle
+    import oracle
+    pwm_r = np.round(rng.normal(0, 1, (4, 300)), 3)
+    for _ in range(2):
+        resw, _ = align_window_offsets(chrom, starts, lens, 3.5, 1.25, pwm_r, device=local_rank, want_traceback=False, want_alignments=False, reuse=keep)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        resw, _ = align_window_offsets(chrom, starts, lens, 3.5, 1.25, pwm_r, device=local_rank, want_traceback=False, want_alignments=False, reuse=keep)
+        ts.append(time.perf_counter() - t0)
+    dtw = sorted(ts)[1]
+    samp = range(0, 100000, 997)
+    same = sum(1 for i in samp if float(resw["f"][i]) == oracle.align_pwm(chrom[i * 30:i * 30 + 330], 3.5, 1.25, pwm_r)["f"])
+    out["pwm_windows_real_valued"] = {"workload": "the same 100000 windows x a real-valued 4 x 300 PWM (normal weights, 3 decimals), del 3.5 / ext 1.25, "
+                                                  "score only, host buffers in and out: f64 kernels",
+                                      "ms": round(dtw * 1e3, 2), "gcups": round(100000 * 330 * 300 / dtw / 1e9, 2),
+                                      "integer_kernels": bool((resw["flags"] & 1).all()), "windows_ok": int((resw["status"] == 0).sum()),
+                                      "windows_filled_twice": int(((resw["passes"] & 0xff) >= 2).sum()),
+                                      "sample_windows_equal_oracle": "%d of %d" % (same, len(samp))}
     # C3: 10 000 nucleotide read pairs 150 x 150, core global, +5/-4, 10/1
     b3 = workloads.c3_batch(10000)
     dt, tm, r, dirs = staged(b3, _ffi.CORE_GLOBAL, 10, 1, nucleotide_matrix(), 50)

@@ -15,7 +15,7 @@ else:
         env = dict(os.environ); env.update(kw); subprocess.check_call([sys.executable, __file__, "/tmp/p_%s.npy" % tag], env=env)
         return np.load("/tmp/p_%s.npy" % tag)
     o = run("old", ALN_F64_OLD="1")
-    for tag, kw in (("new1", {}), ("always_look", {"ALN_COOP_DEBUG": "8"}), ("lane_thr", {"ALN_COOP_DEBUG": "16"}), ("both", {"ALN_COOP_DEBUG": "24"})):
+    for tag, kw in (("new", {}), ("new_768_workgroups", {"ALN_FILL_WGS": "768"})):
         a = run(tag, **kw)
         d = np.nonzero(a[0] != o[0])[0]
         print(tag, "differ", len(d), "of", a.shape[1], "score equal", (a[3] == o[3]).all(), "first", d[:12])
