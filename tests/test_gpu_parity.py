@@ -162,6 +162,34 @@ def test_f64_kernels_match_oracle(orc, blosum62, sem, shape):
     assert res is None or (res.flags & 1) == 0
 
 
+@pytest.mark.parametrize("sem", [_ffi.CORE_GLOBAL, _ffi.CORE_LOCAL])
+@pytest.mark.parametrize("gaps", [(11.3, 2.1), (3.3, 3.3)])
+def test_real_valued_batch_on_the_lean_f64_strip(orc, blosum62, monkeypatch, sem, gaps):
+    """Real-valued batches of the core semantics run aln_fill_f64_kernel (the lean f64 strip: asm cell blocks, tags through carry
+    masks, wave-wide end-cell threshold).  90 pairs of 1..1400 residues (one to three strips, every R of the last
+    strip), related and unrelated, BLOSUM62 x 0.37: summaries and strings against the oracle, and record for record -- the number
+    of advice passes included -- against run_strip's loop in the same build (ALN_F64_OLD=1: a scalar condition code lost across an
+    asm block once showed only as extra passes)."""
+    rng = np.random.default_rng(370 + sem)
+    pairs = []
+    for i in range(90):
+        N, M = int(rng.integers(1, 1400)), int(rng.integers(1, 1400))
+        q = rng.integers(0, 20, N).astype(np.uint8)
+        t = rng.integers(0, 20, M).astype(np.uint8)
+        if i % 2 and min(N, M) > 8:
+            L = min(N, M) // 2
+            t[M // 4:M // 4 + L] = q[N // 4:N // 4 + L][:len(t[M // 4:M // 4 + L])]
+        pairs.append((q, t))
+    b = PairBatch.from_pairs(pairs)
+    S = blosum62 * 0.37
+    got = _check_batch(orc, b, sem, gaps[0], gaps[1], S)
+    assert not (got.results["flags"] & 1).any()
+    monkeypatch.setenv("ALN_F64_OLD", "1")
+    old = align_batch(b, sem, gaps[0], gaps[1], S)
+    for f in ("status", "score", "f", "end_y", "end_x", "start_y", "start_x", "aln_len", "passes"):
+        assert (got.results[f] == old.results[f]).all(), f
+
+
 @pytest.mark.parametrize("sem", SEMS)
 @pytest.mark.parametrize("shape", [(300, 600), (1000, 1000), (260, 65), (700, 1500), (2100, 2048), (16, 1024)])
 def test_generic_pair_filled_by_one_workgroup(orc, blosum62, sem, shape):
