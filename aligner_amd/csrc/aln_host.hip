@@ -1611,7 +1611,10 @@ extern "C" int aln_align_pair(aln_ctx *ctx, const aln_params *params, const uint
     struct Release { DevCtx *c; Slot **s; ~Release() { pool_release(c, s, 1); } } rel{dev, sl};
     Slot &s = *sl[0];
     Chunk k;
-    if ((st = chunk_plan(dev, c, &qo, &ql, &to, &tl, 0, 1, false, k)) != ALN_OK) return st;
+    // (allow_overlap = true: a pair that misses the single-pair route -- more than ~77 000 columns -- opens its first pass for other waves
+    // like a one-pair batch call does: 200 000 x 5000 ran on ONE wave at 1.8 GCUPS before, the reference's only limit being memory,
+    // simple/mod.rs:53-57)
+    if ((st = chunk_plan(dev, c, &qo, &ql, &to, &tl, 0, 1, true, k)) != ALN_OK) return st;
     k.seq_direct = false;                                    // query and target are two caller buffers: gathered into staging
     k.seq_span = nq + M;
     k.descs[0].q_off = 0; k.descs[0].t_off = nq;
